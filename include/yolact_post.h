@@ -1,0 +1,130 @@
+/*
+ * libyolact_post.so - C ABI of the MI355X (gfx950) YOLACT post-processing path.
+ *
+ * The reference (anshkumar/yolact, TensorFlow 2) has no FFI/plugin interface on
+ * this path: the unit of replacement is the Python class `Detect`
+ * (detection.py:6-117) that `Yolact.call` invokes at yolact.py:192.  The entry
+ * points below are what a ctypes binding of that class needs; each one cites the
+ * reference interface it stands in for.  yolact_amd/detect.py is that binding
+ * and INTEGRATION.md shows the stub a maintainer would add to yolact.py.
+ *
+ * Conventions: plain pointers and sizes only; every function returns 0 on
+ * success and a negative YP_E* code on failure (text: yp_last_error(), per
+ * thread); no exceptions cross the ABI.  All tensor pointers are DEVICE
+ * pointers on the handle's device, fp32, C-contiguous.  The caller owns every
+ * input/output buffer; the handle owns its scratch.  yp_run is asynchronous on
+ * `hip_stream` and allocates nothing.  One handle serves one stream at a time;
+ * distinct handles are independent (one per GPU when sharding a batch).
+ * There is no CPU backend: without a HIP device yp_create fails.
+ */
+#ifndef YOLACT_POST_H
+#define YOLACT_POST_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define YP_VERSION 100 /* 0.1.0 */
+
+enum {
+  YP_OK = 0,
+  YP_EINVAL = -1,   /* bad argument / unsupported shape            */
+  YP_ENODEV = -2,   /* no HIP device / bad device id               */
+  YP_ENOMEM = -3,   /* scratch allocation failed                   */
+  YP_EHIP = -4      /* a HIP runtime call failed                   */
+};
+
+enum {
+  YP_NMS_CROSS_CLASS = 0, /* Detect._cc_fast_nms, detection.py:181-209 (the live path) */
+  YP_NMS_PER_CLASS = 1    /* intent of Detect._fast_nms, detection.py:211-250 (dead code;
+                             per-class top_k + cross-class top max_dets, 1-based class ids) */
+};
+
+/* Immutable after yp_create.  Mirrors Detect.__init__ (detection.py:13-22) plus the shapes
+ * Detect.__call__ reads dynamically (detection.py:44-53) and the literals it hard-codes. */
+typedef struct yp_config {
+  int32_t num_anchors;      /* A: pred_cls.shape[1]                                   */
+  int32_t num_classes;      /* C incl. background: pred_cls.shape[2] (2..256)         */
+  int32_t mask_dim;         /* K: pred_mask_coef.shape[2]; must be 32                 */
+  int32_t proto_h, proto_w; /* proto_out.shape[1:3]                                   */
+  int32_t img_h, img_w;     /* img_shape[1], img_shape[2] (detection.py:92-98)        */
+  float conf_thresh;        /* Detect.conf_thresh, strict '>' (detection.py:73)       */
+  float nms_thresh;         /* IoU threshold, '<=' keeps (detection.py:202); the live
+                               reference always uses 0.5 here                          */
+  int32_t nms_mode;         /* YP_NMS_*                                               */
+  int32_t top_k;            /* _cc_fast_nms top_k (15 in the reference); 1..256       */
+  int32_t max_dets;         /* rows per image in every output (row stride); the first
+                               min(kept, max_dets) score-descending detections are
+                               written.  Reference layout: 300 (detection.py:21)       */
+  int32_t use_cropped_mask; /* detection.py:102 (1 in every reference call)            */
+  int32_t zero_pad_masks;   /* 1: mask rows >= num_det are written as zeros, which is
+                               the reference's tf.zeros layout (detection.py:68);
+                               0: those rows are left untouched                        */
+  float mask_threshold;     /* < 0: float masks only.  >= 0: det_bitmaps = mask > thr
+                               (the callers' binarisation, train.py:497)               */
+  int32_t max_batch;        /* largest batch yp_run will be given                      */
+  int32_t device_id;        /* HIP device ordinal, >= 0                                */
+} yp_config;
+
+typedef struct yp_handle yp_handle;
+
+/* Detect.__init__ (detection.py:13-22).  Validates like it (nms_thresh <= 0 is
+ * YP_EINVAL, cf. the ValueError at L17-18) and allocates the device scratch. */
+int yp_create(const yp_config* cfg, yp_handle** out);
+
+/* Releases the scratch.  (Python: the object going out of scope.) */
+int yp_destroy(yp_handle* h);
+
+/* Detect.__call__ (detection.py:24-117) for `batch` images.
+ *   inputs  (net_outs, detection.py:44-48):
+ *     pred_offset [batch,A,4]  pred_cls [batch,A,C] raw logits  pred_mask_coef [batch,A,K]
+ *     priors [A,4] = [ymin,xmin,ymax,xmax] pixels               proto [batch,ph,pw,K]
+ *   outputs (result dict, detection.py:116), row stride max_dets:
+ *     det_boxes   [batch,max_dets,4]  normalised [ymin,xmin,ymax,xmax]   (L93-98, L110)
+ *     det_classes [batch,max_dets]    float, 1-based, 0 = empty          (L111)
+ *     det_scores  [batch,max_dets]    descending in the filled prefix    (L112)
+ *     det_masks   [batch,max_dets,ph,pw] float in [0,1]; may be NULL     (L113)
+ *     det_bitmaps [batch,max_dets,ph,pw] uint8, NULL unless mask_threshold >= 0
+ *     num_det     [batch] int32                                          (L114)
+ *     kept_anchor_idx [batch,max_dets] int32, original anchor index of each kept
+ *                 detection, -1 padded (not exposed by the reference; may be NULL)
+ *   Rows >= num_det of boxes/classes/scores are zero.  Asynchronous on hip_stream
+ *   (NULL = the default stream). */
+int yp_run(yp_handle* h, int32_t batch,
+           const float* pred_offset, const float* pred_cls, const float* pred_mask_coef,
+           const float* priors, const float* proto,
+           float* det_boxes, float* det_classes, float* det_scores,
+           float* det_masks, uint8_t* det_bitmaps,
+           int32_t* num_det, int32_t* kept_anchor_idx,
+           void* hip_stream);
+
+/* Blocks until the handle's last yp_run has finished.  (TF: fetching the tensors.) */
+int yp_sync(yp_handle* h);
+
+/* Number of anchors that passed the confidence filter (tf.boolean_mask, detection.py:73)
+ * per image of the LAST yp_run; synchronises.  host_out: [batch] int32 on the host. */
+int yp_last_survivors(yp_handle* h, int32_t* host_out, int32_t batch);
+
+/* Per-kernel timing for benchmarks (no reference counterpart).  When enabled, yp_run brackets
+ * each kernel with HIP events on hip_stream; yp_profile_read synchronises and returns the
+ * last run's durations in milliseconds: [0] score_filter [1] segment_nms [2] final_select
+ * (0 in cross-class mode) [3] mask_assemble. */
+#define YP_NUM_KERNELS 4
+int yp_profile_enable(yp_handle* h, int32_t on);
+int yp_profile_read(yp_handle* h, float* ms_out /* [YP_NUM_KERNELS] */);
+
+/* Bytes of device scratch the handle holds. */
+int64_t yp_scratch_bytes(const yp_handle* h);
+
+/* Text of the calling thread's last error ("" if none). */
+const char* yp_last_error(void);
+
+/* YP_VERSION of the loaded library. */
+int yp_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* YOLACT_POST_H */

@@ -1,0 +1,181 @@
+// C ABI of libyolact_post.so (declared in include/yolact_post.h).  Host side only: argument
+// validation, scratch carving, stream-ordered launches.  No CPU compute path exists.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <new>
+
+#include "common.hpp"
+
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define YP_HIP(call)                                                                              \
+  do {                                                                                            \
+    hipError_t e_ = (call);                                                                       \
+    if (e_ != hipSuccess) return fail(YP_EHIP, "%s failed: %s", #call, hipGetErrorString(e_));    \
+  } while (0)
+
+static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+extern "C" const char* yp_last_error(void) { return g_err; }
+extern "C" int yp_version(void) { return YP_VERSION; }
+
+extern "C" int yp_create(const yp_config* cfg, yp_handle** out) {
+  if (!cfg || !out) return fail(YP_EINVAL, "yp_create: null argument");
+  *out = nullptr;
+  const yp_config& c = *cfg;
+  if (c.nms_thresh <= 0.0f) return fail(YP_EINVAL, "nms_threshold must be non negative.");   // detection.py:17-18
+  if (c.num_anchors < 1 || c.num_anchors > (1 << 24)) return fail(YP_EINVAL, "num_anchors must be in [1, 2^24]");
+  if (c.num_classes < 2 || c.num_classes > 256) return fail(YP_EINVAL, "num_classes (incl. background) must be in [2, 256]");
+  if (c.mask_dim != YP_MASK_DIM) return fail(YP_EINVAL, "mask_dim must be %d", YP_MASK_DIM);
+  if (c.proto_h < 1 || c.proto_w < 1 || c.img_h < 1 || c.img_w < 1) return fail(YP_EINVAL, "bad proto/image size");
+  if (c.nms_mode != YP_NMS_CROSS_CLASS && c.nms_mode != YP_NMS_PER_CLASS) return fail(YP_EINVAL, "bad nms_mode");
+  if (c.top_k < 1 || c.top_k > YP_SORT_MAX) return fail(YP_EINVAL, "top_k must be in [1, %d]", YP_SORT_MAX);
+  if (c.max_dets < 1) return fail(YP_EINVAL, "max_dets must be >= 1");
+  if (c.nms_mode == YP_NMS_PER_CLASS && c.max_dets > YP_SORT_MAX)
+    return fail(YP_EINVAL, "per-class mode: max_dets must be <= %d", YP_SORT_MAX);
+  if (c.max_batch < 1) return fail(YP_EINVAL, "max_batch must be >= 1");
+  if (!(c.conf_thresh >= 0.0f && c.conf_thresh < 1.0f)) return fail(YP_EINVAL, "conf_thresh must be in [0, 1)");
+
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(YP_ENODEV, "no HIP device available");
+  if (c.device_id < 0 || c.device_id >= ndev) return fail(YP_ENODEV, "device_id %d out of range (%d devices)", c.device_id, ndev);
+  YP_HIP(hipSetDevice(c.device_id));
+
+  yp_handle* h = new (std::nothrow) yp_handle();
+  if (!h) return fail(YP_ENOMEM, "host allocation failed");
+  memset(h, 0, sizeof(*h));
+  h->cfg = c;
+  h->nseg = c.nms_mode == YP_NMS_CROSS_CLASS ? 1 : c.num_classes - 1;
+  h->sel_rows = c.max_dets < YP_SORT_MAX ? c.max_dets : YP_SORT_MAX;
+  h->lds_stride = (c.num_classes & 1) ? c.num_classes : c.num_classes + 1;   // odd stride: conflict-free rows
+  if ((size_t)YP_WAVE * h->lds_stride * sizeof(float) > 64 * 1024) { delete h; return fail(YP_EINVAL, "num_classes too large for the LDS tile"); }
+
+  const size_t B = (size_t)c.max_batch, A = (size_t)c.num_anchors, nseg = (size_t)h->nseg;
+  const size_t pool_cap = c.nms_mode == YP_NMS_PER_CLASS ? nseg * (size_t)c.top_k : 0;
+  size_t off = 0;
+  const size_t o_cand = off;  off = align_up(off + B * nseg * A * sizeof(u64), 256);
+  const size_t o_box = off;   off = align_up(off + B * A * sizeof(float4), 256);
+  const size_t o_pool = off;  off = align_up(off + B * pool_cap * sizeof(u64), 256);
+  const size_t o_crop = off;  off = align_up(off + B * h->sel_rows * sizeof(float4), 256);
+  const size_t o_coef = off;  off = align_up(off + B * h->sel_rows * YP_MASK_DIM * sizeof(float), 256);
+  const size_t o_cnt = off;   // all counters contiguous so one memset clears them
+  const size_t n_cnt = B * nseg + 3 * B;
+  off = align_up(off + n_cnt * sizeof(int32_t), 256);
+  h->scratch_bytes = (int64_t)off;
+  if (hipMalloc(&h->scratch_base, off) != hipSuccess) {
+    delete h;
+    return fail(YP_ENOMEM, "hipMalloc of %zu scratch bytes failed", off);
+  }
+  char* base = (char*)h->scratch_base;
+  h->s.cand = (u64*)(base + o_cand);
+  h->s.dec_box = (float4*)(base + o_box);
+  h->s.pool = (u64*)(base + o_pool);
+  h->s.crop = (float4*)(base + o_crop);
+  h->s.coef = (float*)(base + o_coef);
+  h->s.cand_count = (int32_t*)(base + o_cnt);
+  h->s.surv_count = h->s.cand_count + B * nseg;
+  h->s.stat_surv = h->s.surv_count + B;
+  h->s.pool_count = h->s.stat_surv + B;
+  if (hipMemset(h->s.cand_count, 0, n_cnt * sizeof(int32_t)) != hipSuccess) {
+    (void)hipFree(h->scratch_base);
+    delete h;
+    return fail(YP_EHIP, "hipMemset of the counters failed");
+  }
+  (void)hipDeviceSynchronize();   // the counters are zero before any stream can run score_filter
+  *out = h;
+  g_err[0] = 0;
+  return YP_OK;
+}
+
+extern "C" int yp_destroy(yp_handle* h) {
+  if (!h) return YP_OK;
+  (void)hipSetDevice(h->cfg.device_id);
+  (void)hipDeviceSynchronize();
+  if (h->profile) for (int i = 0; i <= YP_NUM_KERNELS; ++i) (void)hipEventDestroy(h->ev[i]);
+  (void)hipFree(h->scratch_base);
+  delete h;
+  return YP_OK;
+}
+
+extern "C" int yp_run(yp_handle* h, int32_t batch, const float* pred_offset, const float* pred_cls,
+                      const float* pred_mask_coef, const float* priors, const float* proto, float* det_boxes,
+                      float* det_classes, float* det_scores, float* det_masks, uint8_t* det_bitmaps,
+                      int32_t* num_det, int32_t* kept_anchor_idx, void* hip_stream) {
+  if (!h) return fail(YP_EINVAL, "yp_run: null handle");
+  if (batch < 0 || batch > h->cfg.max_batch) return fail(YP_EINVAL, "batch %d outside [0, max_batch=%d]", batch, h->cfg.max_batch);
+  if (!pred_offset || !pred_cls || !pred_mask_coef || !priors || !det_boxes || !det_classes || !det_scores || !num_det)
+    return fail(YP_EINVAL, "yp_run: null tensor pointer");
+  if (det_masks && !proto) return fail(YP_EINVAL, "yp_run: det_masks given without proto");
+  if (det_bitmaps && (!det_masks || h->cfg.mask_threshold < 0.0f))
+    return fail(YP_EINVAL, "yp_run: det_bitmaps needs det_masks and mask_threshold >= 0");
+  if ((((uintptr_t)pred_offset | (uintptr_t)priors | (uintptr_t)pred_mask_coef | (uintptr_t)det_boxes | (uintptr_t)proto) & 15u) != 0)
+    return fail(YP_EINVAL, "yp_run: pred_offset, priors, pred_mask_coef, proto and det_boxes must be 16-byte aligned");
+  if (batch == 0) return YP_OK;
+  hipStream_t st = (hipStream_t)hip_stream;
+  YP_HIP(hipSetDevice(h->cfg.device_id));
+  h->last_stream = st;
+  h->last_batch = batch;
+  const bool prof = h->profile != 0;
+  if (prof) YP_HIP(hipEventRecord(h->ev[0], st));
+  YP_HIP(yp_launch_score_filter(h, batch, pred_cls, pred_offset, priors, st));
+  if (prof) YP_HIP(hipEventRecord(h->ev[1], st));
+  YP_HIP(yp_launch_segment_nms(h, batch, pred_mask_coef, det_boxes, det_classes, det_scores, num_det, kept_anchor_idx, st));
+  if (prof) YP_HIP(hipEventRecord(h->ev[2], st));
+  if (h->cfg.nms_mode == YP_NMS_PER_CLASS)
+    YP_HIP(yp_launch_final_select(h, batch, pred_mask_coef, det_boxes, det_classes, det_scores, num_det, kept_anchor_idx, st));
+  if (prof) YP_HIP(hipEventRecord(h->ev[3], st));
+  if (det_masks) YP_HIP(yp_launch_mask_assemble(h, batch, proto, num_det, det_masks, det_bitmaps, st));
+  if (prof) YP_HIP(hipEventRecord(h->ev[4], st));
+  return YP_OK;
+}
+
+extern "C" int yp_sync(yp_handle* h) {
+  if (!h) return fail(YP_EINVAL, "yp_sync: null handle");
+  YP_HIP(hipSetDevice(h->cfg.device_id));
+  YP_HIP(hipStreamSynchronize(h->last_stream));
+  return YP_OK;
+}
+
+extern "C" int yp_last_survivors(yp_handle* h, int32_t* host_out, int32_t batch) {
+  if (!h || !host_out) return fail(YP_EINVAL, "yp_last_survivors: null argument");
+  if (batch < 0 || batch > h->cfg.max_batch) return fail(YP_EINVAL, "bad batch");
+  YP_HIP(hipSetDevice(h->cfg.device_id));
+  YP_HIP(hipStreamSynchronize(h->last_stream));
+  YP_HIP(hipMemcpy(host_out, h->s.stat_surv, sizeof(int32_t) * (size_t)batch, hipMemcpyDeviceToHost));
+  return YP_OK;
+}
+
+extern "C" int yp_profile_enable(yp_handle* h, int32_t on) {
+  if (!h) return fail(YP_EINVAL, "yp_profile_enable: null handle");
+  YP_HIP(hipSetDevice(h->cfg.device_id));
+  if (on && !h->profile) {
+    for (int i = 0; i <= YP_NUM_KERNELS; ++i) YP_HIP(hipEventCreate(&h->ev[i]));
+    h->profile = 1;
+  } else if (!on && h->profile) {
+    YP_HIP(hipStreamSynchronize(h->last_stream));
+    for (int i = 0; i <= YP_NUM_KERNELS; ++i) (void)hipEventDestroy(h->ev[i]);
+    h->profile = 0;
+  }
+  return YP_OK;
+}
+
+extern "C" int yp_profile_read(yp_handle* h, float* ms_out) {
+  if (!h || !ms_out) return fail(YP_EINVAL, "yp_profile_read: null argument");
+  if (!h->profile) return fail(YP_EINVAL, "profiling is not enabled");
+  YP_HIP(hipSetDevice(h->cfg.device_id));
+  YP_HIP(hipEventSynchronize(h->ev[YP_NUM_KERNELS]));
+  for (int i = 0; i < YP_NUM_KERNELS; ++i) YP_HIP(hipEventElapsedTime(&ms_out[i], h->ev[i], h->ev[i + 1]));
+  return YP_OK;
+}
+
+extern "C" int64_t yp_scratch_bytes(const yp_handle* h) { return h ? h->scratch_bytes : 0; }

@@ -1,0 +1,123 @@
+// Shared declarations of libyolact_post.so (gfx950 only).
+//
+// Arithmetic contract "YP-MATH" (DESIGN.md section 3): every value the decisions of the
+// reference depend on (scores, decoded boxes, IoU) is computed with single IEEE f32
+// operations in the order the reference's Python expressions evaluate them, an explicit-fma
+// Cephes exp, a fixed softmax reduction tree and IEEE division.  All translation units are
+// built with -ffp-contract=off; fma is only ever written explicitly.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/yolact_post.h"
+
+#pragma clang fp contract(off)
+
+typedef unsigned long long u64;
+
+#define YP_WAVE 64
+#define YP_SORT_MAX 256   // largest top_k / final selection handled by one workgroup sort
+#define YP_MASK_DIM 32
+
+// ---- candidate keys -----------------------------------------------------------------------
+// A candidate is one 64-bit key whose unsigned order is the order tf.math.top_k imposes
+// (detection.py:186: score descending, ties -> lower index first).
+//   segment key (score_filter -> segment_nms):  [score bits:32][0xFFFFFF - anchor:24][class:8]
+//   final key   (segment_nms -> final_select):  [score bits:32][255 - class:8][0xFFFFFF - anchor:24]
+// Scores are positive floats, so their bit patterns order like their values.
+__host__ __device__ inline u64 yp_seg_key(float score, int anchor, int cls) {
+  return ((u64)__builtin_bit_cast(uint32_t, score) << 32) | ((u64)(0xFFFFFFu - (uint32_t)anchor) << 8) | (u64)(uint32_t)cls;
+}
+__host__ __device__ inline float yp_key_score(u64 k) { return __builtin_bit_cast(float, (uint32_t)(k >> 32)); }
+__host__ __device__ inline int yp_seg_key_anchor(u64 k) { return (int)(0xFFFFFFu - (uint32_t)((k >> 8) & 0xFFFFFFu)); }
+__host__ __device__ inline int yp_seg_key_class(u64 k) { return (int)(k & 0xFFu); }
+__host__ __device__ inline u64 yp_fin_key(float score, int anchor, int cls) {
+  return ((u64)__builtin_bit_cast(uint32_t, score) << 32) | ((u64)(255u - (uint32_t)cls) << 24) | (u64)(0xFFFFFFu - (uint32_t)anchor);
+}
+__host__ __device__ inline int yp_fin_key_anchor(u64 k) { return (int)(0xFFFFFFu - (uint32_t)(k & 0xFFFFFFu)); }
+__host__ __device__ inline int yp_fin_key_class(u64 k) { return (int)(255u - (uint32_t)((k >> 24) & 0xFFu)); }
+
+#ifdef __HIPCC__
+// ---- YP-MATH device functions -------------------------------------------------------------
+__device__ __forceinline__ float yp_exp(float x) {
+  x = fminf(fmaxf(x, -87.0f), 87.0f);
+  const float fx = floorf(__builtin_fmaf(x, 1.44269504088896341f, 0.5f));
+  float r = __builtin_fmaf(fx, -0.693359375f, x);
+  r = __builtin_fmaf(fx, 2.12194440e-4f, r);
+  const float z = r * r;
+  float y = 1.9875691500E-4f;
+  y = __builtin_fmaf(y, r, 1.3981999507E-3f);
+  y = __builtin_fmaf(y, r, 8.3334519073E-3f);
+  y = __builtin_fmaf(y, r, 4.1665795894E-2f);
+  y = __builtin_fmaf(y, r, 1.6666665459E-1f);
+  y = __builtin_fmaf(y, r, 5.0000001201E-1f);
+  y = __builtin_fmaf(y, z, r);
+  y = y + 1.0f;
+  const int n = (int)fx;
+  return y * __builtin_bit_cast(float, (uint32_t)(n + 127) << 23);
+}
+
+__device__ __forceinline__ float yp_sigmoid(float x) { return 1.0f / (1.0f + yp_exp(-x)); }
+
+__device__ __forceinline__ float yp_clip(float t, float lo, float hi) { return fminf(fmaxf(t, lo), hi); }
+
+// utils._iou for one pair (utils/utils.py:19-21, 40-48, 63-70); boxes are (ymin,xmin,ymax,xmax).
+__device__ __forceinline__ float yp_iou(const float4 a, const float4 b) {
+  const float area1 = (a.z - a.x) * (a.w - a.y);
+  const float area2 = (b.z - b.x) * (b.w - b.y);
+  const float ih = fmaxf(0.0f, fminf(a.z, b.z) - fmaxf(a.x, b.x));
+  const float iw = fmaxf(0.0f, fminf(a.w, b.w) - fmaxf(a.y, b.y));
+  const float inter = ih * iw;
+  const float uni = (area1 + area2) - inter;
+  return inter == 0.0f ? 0.0f : inter / uni;
+}
+
+// utils.sanitize_coordinates (utils/utils.py:89-104).
+__device__ __forceinline__ void yp_sanitize(float a, float b, float img_size, bool normalized, float padding,
+                                            float& x1, float& x2) {
+  if (normalized) { a = a * img_size; b = b * img_size; }
+  const float lo = fminf(a, b), hi = fmaxf(a, b);
+  x1 = yp_clip(lo - padding, 0.0f, img_size);
+  x2 = yp_clip(hi + padding, 0.0f, img_size);
+}
+#endif  // __HIPCC__
+
+// ---- device scratch owned by a handle -----------------------------------------------------
+struct yp_scratch {
+  u64* cand;            // [max_batch][nseg][A] candidate keys, unordered within a segment
+  int32_t* cand_count;  // [max_batch][nseg]   (zero between runs; consumed + reset by segment_nms)
+  int32_t* surv_count;  // [max_batch] anchors past the confidence filter (reset by the last consumer)
+  int32_t* stat_surv;   // [max_batch] copy kept for yp_last_survivors
+  float4* dec_box;      // [max_batch][A] decoded boxes, written at survivor anchors only
+  u64* pool;            // [max_batch][Cfg*top_k] per-class NMS survivors (per-class mode)
+  int32_t* pool_count;  // [max_batch]
+  float4* crop;         // [max_batch][sel_rows] (x1,x2,y1,y2) crop edges in proto pixels
+  float* coef;          // [max_batch][sel_rows][32] coefficients of the kept detections
+};
+
+struct yp_handle {
+  yp_config cfg;
+  int nseg;             // segments per image: 1 (cross-class) or C-1 (per-class)
+  int sel_rows;         // min(max_dets, YP_SORT_MAX): rows a detection can land in
+  int lds_stride;       // floats per anchor row in score_filter's LDS tile
+  void* scratch_base;
+  int64_t scratch_bytes;
+  yp_scratch s;
+  hipStream_t last_stream;
+  int last_batch;
+  int profile;
+  hipEvent_t ev[YP_NUM_KERNELS + 1];
+};
+
+// Kernel launchers (one per translation unit).  All asynchronous on `st`.
+hipError_t yp_launch_score_filter(const yp_handle* h, int batch, const float* pred_cls, const float* pred_offset,
+                                  const float* priors, hipStream_t st);
+hipError_t yp_launch_segment_nms(const yp_handle* h, int batch, const float* pred_mask_coef, float* det_boxes,
+                                 float* det_classes, float* det_scores, int32_t* num_det, int32_t* kept_idx,
+                                 hipStream_t st);
+hipError_t yp_launch_final_select(const yp_handle* h, int batch, const float* pred_mask_coef, float* det_boxes,
+                                  float* det_classes, float* det_scores, int32_t* num_det, int32_t* kept_idx,
+                                  hipStream_t st);
+hipError_t yp_launch_mask_assemble(const yp_handle* h, int batch, const float* proto, const int32_t* num_det,
+                                   float* det_masks, uint8_t* det_bitmaps, hipStream_t st);
