@@ -1,7 +1,9 @@
 // C ABI of libyolact_post.so (declared in include/yolact_post.h).  Host side only: argument
 // validation, scratch carving, stream-ordered launches.  No CPU compute path exists.
+#include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <new>
@@ -58,18 +60,31 @@ extern "C" int yp_create(const yp_config* cfg, yp_handle** out) {
   h->nseg = c.nms_mode == YP_NMS_CROSS_CLASS ? 1 : c.num_classes - 1;
   h->sel_rows = c.max_dets < YP_SORT_MAX ? c.max_dets : YP_SORT_MAX;
   h->lds_stride = (c.num_classes & 1) ? c.num_classes : c.num_classes + 1;   // odd stride: conflict-free rows
+  {
+    // p_fgmax <= 1/(1+exp(x_bg-x_fgmax)) > conf  <=>  x_bg-x_fgmax < ln(1/conf-1); +1e-3 covers rounding
+    const double cf = (double)c.conf_thresh;
+    h->pre_thresh = cf > 0.0 ? (float)(log(1.0 / cf - 1.0) + 1e-3) : INFINITY;
+  }
+  h->tile_anchors = 32;
+  if (const char* ev = getenv("YP_TILE_ANCHORS")) {   // tuning knob for benchmarks
+    const int v = atoi(ev);
+    if (v == 16 || v == 32 || v == 64) h->tile_anchors = v;
+  }
   if ((size_t)YP_WAVE * h->lds_stride * sizeof(float) > 64 * 1024) { delete h; return fail(YP_EINVAL, "num_classes too large for the LDS tile"); }
 
+  h->ntiles = (c.num_anchors + h->tile_anchors - 1) / h->tile_anchors;
   const size_t B = (size_t)c.max_batch, A = (size_t)c.num_anchors, nseg = (size_t)h->nseg;
-  const size_t pool_cap = c.nms_mode == YP_NMS_PER_CLASS ? nseg * (size_t)c.top_k : 0;
+  const bool per_class = c.nms_mode == YP_NMS_PER_CLASS;
+  const size_t cand_per_img = per_class ? nseg * A : (size_t)h->ntiles * h->tile_anchors;
+  const size_t pool_per_img = per_class ? nseg * (size_t)c.top_k : 0;
   size_t off = 0;
-  const size_t o_cand = off;  off = align_up(off + B * nseg * A * sizeof(u64), 256);
+  const size_t o_cand = off;  off = align_up(off + B * cand_per_img * sizeof(u64), 256);
   const size_t o_box = off;   off = align_up(off + B * A * sizeof(float4), 256);
-  const size_t o_pool = off;  off = align_up(off + B * pool_cap * sizeof(u64), 256);
+  const size_t o_pool = off;  off = align_up(off + B * pool_per_img * sizeof(u64), 256);
   const size_t o_crop = off;  off = align_up(off + B * h->sel_rows * sizeof(float4), 256);
   const size_t o_coef = off;  off = align_up(off + B * h->sel_rows * YP_MASK_DIM * sizeof(float), 256);
   const size_t o_cnt = off;   // all counters contiguous so one memset clears them
-  const size_t n_cnt = B * nseg + 3 * B;
+  const size_t n_cnt = 2 * B * nseg + B * (size_t)h->ntiles + B;
   off = align_up(off + n_cnt * sizeof(int32_t), 256);
   h->scratch_bytes = (int64_t)off;
   if (hipMalloc(&h->scratch_base, off) != hipSuccess) {
@@ -83,9 +98,9 @@ extern "C" int yp_create(const yp_config* cfg, yp_handle** out) {
   h->s.crop = (float4*)(base + o_crop);
   h->s.coef = (float*)(base + o_coef);
   h->s.cand_count = (int32_t*)(base + o_cnt);
-  h->s.surv_count = h->s.cand_count + B * nseg;
-  h->s.stat_surv = h->s.surv_count + B;
-  h->s.pool_count = h->s.stat_surv + B;
+  h->s.pool_count = h->s.cand_count + B * nseg;
+  h->s.tile_count = h->s.pool_count + B * nseg;
+  h->s.stat_surv = h->s.tile_count + B * (size_t)h->ntiles;
   if (hipMemset(h->s.cand_count, 0, n_cnt * sizeof(int32_t)) != hipSuccess) {
     (void)hipFree(h->scratch_base);
     delete h;

@@ -85,13 +85,15 @@ __device__ __forceinline__ void yp_sanitize(float a, float b, float img_size, bo
 
 // ---- device scratch owned by a handle -----------------------------------------------------
 struct yp_scratch {
-  u64* cand;            // [max_batch][nseg][A] candidate keys, unordered within a segment
-  int32_t* cand_count;  // [max_batch][nseg]   (zero between runs; consumed + reset by segment_nms)
-  int32_t* surv_count;  // [max_batch] anchors past the confidence filter (reset by the last consumer)
-  int32_t* stat_surv;   // [max_batch] copy kept for yp_last_survivors
+  u64* cand;            // cross-class: [max_batch][ntiles*TA] tile-major slots (tile g keeps its
+                        // tile_count[g] keys at the front of its TA slots);
+                        // per-class: [max_batch][nseg][A] append lists, unordered
+  int32_t* cand_count;  // per-class: [max_batch][nseg] list lengths (zero between runs: class_nms resets)
+  int32_t* tile_count;  // [max_batch][ntiles] survivors per score_filter tile (rewritten every run)
+  int32_t* stat_surv;   // [max_batch] anchors past the confidence filter, for yp_last_survivors
   float4* dec_box;      // [max_batch][A] decoded boxes, written at survivor anchors only
-  u64* pool;            // [max_batch][Cfg*top_k] per-class NMS survivors (per-class mode)
-  int32_t* pool_count;  // [max_batch]
+  u64* pool;            // [max_batch][nseg][top_k] per-class NMS survivors (per-class mode)
+  int32_t* pool_count;  // [max_batch][nseg] (rewritten every run)
   float4* crop;         // [max_batch][sel_rows] (x1,x2,y1,y2) crop edges in proto pixels
   float* coef;          // [max_batch][sel_rows][32] coefficients of the kept detections
 };
@@ -101,6 +103,9 @@ struct yp_handle {
   int nseg;             // segments per image: 1 (cross-class) or C-1 (per-class)
   int sel_rows;         // min(max_dets, YP_SORT_MAX): rows a detection can land in
   int lds_stride;       // floats per anchor row in score_filter's LDS tile
+  float pre_thresh;     // score_filter's early-reject bound on x_bg - x_fgmax
+  int tile_anchors;     // TA: anchors per score_filter wave (16, 32 or 64)
+  int ntiles;           // ceil(A / TA)
   void* scratch_base;
   int64_t scratch_bytes;
   yp_scratch s;

@@ -6,21 +6,27 @@
 // (utils/utils.py:116-117) and the box/class/score scatters of detection.py:109-114.
 //
 // A "segment" is one image (cross-class mode) or one (image, class) pair (per-class mode).  One
-// workgroup owns a segment: it selects the top_k candidate keys (radix select on the 64-bit keys
-// when the segment holds more than 256, otherwise directly), sorts them with a bitonic network in
-// LDS, gathers the <= 256 decoded boxes into LDS and lets thread j reduce max_{i<j} IoU(i,j) in
-// registers - the k x k IoU matrix (160 KB at k=200) is never materialised.  max is order
-// independent, so the result equals the reference's reduce_max over the strict upper triangle.
+// workgroup owns a segment: it selects the top_k candidate keys (MSB-first radix select on the
+// 64-bit keys when the segment holds more than 256, staged in LDS when they fit), sorts them with
+// a bitonic network in LDS, gathers the <= 256 decoded boxes into LDS and lets thread j reduce
+// max_{i<j} IoU(i,j) in registers - the k x k IoU matrix (160 KB at k=200) is never materialised.
+// max is order independent, so the result equals the reference's reduce_max over the strict upper
+// triangle.  Latency-bound kernels: no returning global atomics, candidate and box loads are issued
+// as early as their addresses are known.
 #include "common.hpp"
 
+#define YP_RADIX_BITS 11
+#define YP_RADIX_BINS (1 << YP_RADIX_BITS)
+#define YP_STAGE_CAP 4096
+
 struct NmsArgs {
-  const u64* cand;            // [B,nseg,A]
-  int32_t* cand_count;        // [B,nseg]
-  int32_t* surv_count;        // [B]
+  const u64* cand;            // cross-class: [B, ntiles*TA] slots; per-class: [B,nseg,A] lists
+  int32_t* cand_count;        // per-class: [B,nseg]
+  const int32_t* tile_count;  // [B,ntiles]
   int32_t* stat_surv;         // [B]
   const float4* dec_box;      // [B,A]
-  u64* pool;                  // [B,pool_cap]
-  int32_t* pool_count;        // [B]
+  u64* pool;                  // [B,nseg,top_k] per-class NMS survivors, final-key format
+  int32_t* pool_count;        // [B,nseg]
   float4* crop;               // [B,sel_rows]
   float* coef_out;            // [B,sel_rows,32]
   const float* coef_in;       // [B,A,32]
@@ -29,75 +35,133 @@ struct NmsArgs {
   float* det_scores;          // [B,max_dets]
   int32_t* num_det;           // [B]
   int32_t* kept_idx;          // [B,max_dets] (nullable)
-  int A, nseg, top_k, max_dets, sel_rows, pool_cap;
+  int A, nseg, top_k, max_dets, sel_rows, ntiles, TA;
   float nms_thresh, img_h, img_w, proto_h, proto_w;
   int use_crop;
 };
 
 struct SelectShared {
   u64 key[YP_SORT_MAX];
-  int hist[256];
-  int scan[256];
+  int hist[YP_RADIX_BINS];
+  int wtot[16];
   int sel, need, cnt, fill;
 };
 
-// Leaves the k = min(want, n) largest keys of list[0..n) in sh.key[0..k), descending; returns k.
-// All threads of the workgroup must call it.  Keys are unique and non-zero.
+// ---- key sources ---------------------------------------------------------------------------
+struct ListSrc {   // n contiguous keys (global or LDS)
+  const u64* list;
+  int n;
+  template <int THREADS, class F>
+  __device__ __forceinline__ void for_each(F f) const {
+    for (int i = threadIdx.x; i < n; i += THREADS) f(list[i]);
+  }
+};
+struct SlotSrc {   // nsegs groups of `per` slots; group g holds counts[g] keys at its front
+  const u64* slots;
+  const int32_t* counts;
+  int nsegs, per;
+  template <int THREADS, class F>
+  __device__ __forceinline__ void for_each(F f) const {
+    const int total = nsegs * per;
+    for (int s = threadIdx.x; s < total; s += THREADS) {
+      const int g = s / per;
+      if (s - g * per < counts[g]) f(slots[s]);
+    }
+  }
+};
+
 template <int THREADS>
-__device__ int select_topk_sorted(const u64* __restrict__ list, int n, int want, SelectShared& sh) {
+__device__ int block_sum(int v, int* wtot) {   // wtot: >= THREADS/64 ints of LDS
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) wtot[threadIdx.x >> 6] = v;
+  __syncthreads();
+  int s = 0;
+  for (int w = 0; w < THREADS / 64; ++w) s += wtot[w];
+  return s;
+}
+
+// The k-th largest of n unique keys: on return every key with (key & mask) >= prefix is one of the
+// k largest, and exactly k keys satisfy it.  MSB-first, YP_RADIX_BITS bits per pass, 4 barriers per pass.
+template <int THREADS, class Src>
+__device__ void radix_select(const Src& src, int k, SelectShared& sh, u64& prefix_out, u64& mask_out) {
+  constexpr int BPT = YP_RADIX_BINS / THREADS;   // bins per thread
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  u64 prefix = 0, mask = 0;
+  int need = k;
+  for (int hi = 64; hi > 0; hi -= YP_RADIX_BITS) {
+    const int shift = hi >= YP_RADIX_BITS ? hi - YP_RADIX_BITS : 0;
+    const int bits = hi - shift;
+    const u64 dmask = (1ull << bits) - 1ull;
+#pragma unroll
+    for (int i = 0; i < BPT; ++i) sh.hist[t * BPT + i] = 0;
+    __syncthreads();
+    src.template for_each<THREADS>([&](u64 key) {
+      if ((key & mask) == prefix) atomicAdd(&sh.hist[(int)((key >> shift) & dmask)], 1);
+    });
+    __syncthreads();
+    int loc[BPT];
+    int tsum = 0;
+#pragma unroll
+    for (int i = 0; i < BPT; ++i) { loc[i] = sh.hist[t * BPT + i]; tsum += loc[i]; }
+    int incl = tsum;   // -> sum over lanes >= lane of this wave
+    for (int o = 1; o < 64; o <<= 1) {
+      const int v = __shfl_down(incl, o);
+      if (lane + o < 64) incl += v;
+    }
+    if (lane == 0) sh.wtot[wave] = incl;
+    __syncthreads();
+    int above = incl - tsum;   // keys in higher bins
+    for (int w = wave + 1; w < THREADS / 64; ++w) above += sh.wtot[w];
+#pragma unroll
+    for (int i = BPT - 1; i >= 0; --i) {
+      if (above < need && need <= above + loc[i]) { sh.sel = t * BPT + i; sh.need = need - above; sh.cnt = loc[i]; }
+      above += loc[i];
+    }
+    __syncthreads();
+    prefix |= (u64)sh.sel << shift;
+    mask |= dmask << shift;
+    need = sh.need;
+    if (sh.cnt == need) break;   // every key left in the selected bin is taken (uniform decision)
+  }
+  prefix_out = prefix;
+  mask_out = mask;
+}
+
+// Leaves the k = min(want, n) largest keys of src in sh.key[0..k), descending; returns k.
+// All threads of the workgroup must call it.  Keys are unique and non-zero.  `stage` is an optional
+// LDS buffer of YP_STAGE_CAP keys.
+template <int THREADS, class Src>
+__device__ int select_topk_sorted(const Src& src, int n, int want, SelectShared& sh, u64* stage) {
   const int t = threadIdx.x;
   const int k = min(want, n);
-  int m;  // keys placed in sh.key
+  if (t == 0) sh.fill = 0;
+  if (t < YP_SORT_MAX) sh.key[t] = 0ull;
+  __syncthreads();
+  int m;
   if (n <= YP_SORT_MAX) {
-    if (t < YP_SORT_MAX) sh.key[t] = t < n ? list[t] : 0ull;
+    src.template for_each<THREADS>([&](u64 key) { sh.key[atomicAdd(&sh.fill, 1)] = key; });
     m = n;
+  } else if (stage != nullptr && n <= YP_STAGE_CAP) {
+    src.template for_each<THREADS>([&](u64 key) { stage[atomicAdd(&sh.fill, 1)] = key; });
     __syncthreads();
-  } else {
-    // MSB-first radix select of the k-th largest key, 8 bits per pass.
-    u64 prefix = 0, mask = 0;
-    int need = k;
-    for (int shift = 56; shift >= 0; shift -= 8) {
-      if (t < 256) sh.hist[t] = 0;
-      __syncthreads();
-      for (int i = t; i < n; i += THREADS) {
-        const u64 key = list[i];
-        if ((key & mask) == prefix) atomicAdd(&sh.hist[(int)((key >> shift) & 0xFFull)], 1);
-      }
-      __syncthreads();
-      if (t < 256) sh.scan[t] = sh.hist[t];
-      __syncthreads();
-      for (int o = 1; o < 256; o <<= 1) {   // inclusive suffix sums
-        int v = 0;
-        if (t < 256 && t + o < 256) v = sh.scan[t + o];
-        __syncthreads();
-        if (t < 256) sh.scan[t] += v;
-        __syncthreads();
-      }
-      if (t < 256) {
-        const int above = sh.scan[t] - sh.hist[t];
-        if (above < need && need <= above + sh.hist[t]) { sh.sel = t; sh.need = need - above; sh.cnt = sh.hist[t]; }
-      }
-      __syncthreads();
-      prefix |= (u64)sh.sel << shift;
-      mask |= 0xFFull << shift;
-      need = sh.need;
-      const bool done = sh.cnt == need;
-      __syncthreads();
-      if (done) break;
-    }
     if (t == 0) sh.fill = 0;
-    if (t < YP_SORT_MAX) sh.key[t] = 0ull;
-    __syncthreads();
-    for (int i = t; i < n; i += THREADS) {
-      const u64 key = list[i];
-      if ((key & mask) >= prefix) {
-        const int pos = atomicAdd(&sh.fill, 1);
-        if (pos < YP_SORT_MAX) sh.key[pos] = key;
-      }
-    }
+    const ListSrc ls{stage, n};
+    u64 prefix, mask;
+    radix_select<THREADS>(ls, k, sh, prefix, mask);
+    ls.template for_each<THREADS>([&](u64 key) {
+      if ((key & mask) >= prefix) sh.key[atomicAdd(&sh.fill, 1)] = key;
+    });
     m = k;
-    __syncthreads();
+  } else {
+    u64 prefix, mask;
+    radix_select<THREADS>(src, k, sh, prefix, mask);
+    src.template for_each<THREADS>([&](u64 key) {
+      if ((key & mask) >= prefix) sh.key[atomicAdd(&sh.fill, 1)] = key;
+    });
+    m = k;
   }
+  __syncthreads();
   // bitonic sort, descending, over the next power of two >= m
   int sz = 1;
   while (sz < m) sz <<= 1;
@@ -119,8 +183,8 @@ __device__ int select_topk_sorted(const u64* __restrict__ list, int n, int want,
 
 // Writes output row r of image b (detection.py:92-98, 110-112) and the row's crop edges
 // (utils/utils.py:116-117 with padding 1.0, normalised coordinates: SURVEY.md A12).
-__device__ __forceinline__ void emit_row(const NmsArgs& p, int b, int r, float score, int cls, int anchor) {
-  const float4 bx = p.dec_box[(size_t)b * p.A + anchor];      // ymin,xmin,ymax,xmax pixels
+__device__ __forceinline__ void emit_row(const NmsArgs& p, int b, int r, float score, int cls, int anchor,
+                                         const float4 bx /* ymin,xmin,ymax,xmax pixels */) {
   float x1, x2, y1, y2;
   yp_sanitize(bx.y, bx.w, p.img_w, false, 0.0f, x1, x2);     // detection.py:126
   yp_sanitize(bx.x, bx.z, p.img_h, false, 0.0f, y1, y2);     // detection.py:127
@@ -141,10 +205,16 @@ __device__ __forceinline__ void emit_row(const NmsArgs& p, int b, int r, float s
   p.crop[(size_t)b * p.sel_rows + r] = cb;
 }
 
-// Rows [n, max_dets) of image b: zeros / -1 (detection.py:65-67); then num_det (L114).
+// Rows [n, max_dets) of image b: zeros / -1 (detection.py:65-67); the kept detections' coefficient
+// rows, compacted for mask_assemble (detection.py:206); num_det (L114).
 template <int THREADS>
-__device__ void finish_image(const NmsArgs& p, int b, int n, const int* s_anchor) {
+__device__ void finish_image(const NmsArgs& p, int b, int n, const int* s_anchor, int survivors) {
   const int t = threadIdx.x;
+  for (int i = t; i < n * (YP_MASK_DIM / 4); i += THREADS) {
+    const int r = i / (YP_MASK_DIM / 4), q = i % (YP_MASK_DIM / 4);
+    const float4 v = reinterpret_cast<const float4*>(p.coef_in + ((size_t)b * p.A + s_anchor[r]) * YP_MASK_DIM)[q];
+    reinterpret_cast<float4*>(p.coef_out + ((size_t)b * p.sel_rows + r) * YP_MASK_DIM)[q] = v;
+  }
   for (int r = n + t; r < p.max_dets; r += THREADS) {
     const size_t o = (size_t)b * p.max_dets + r;
     reinterpret_cast<float4*>(p.det_boxes)[o] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -152,139 +222,193 @@ __device__ void finish_image(const NmsArgs& p, int b, int n, const int* s_anchor
     p.det_scores[o] = 0.0f;
     if (p.kept_idx) p.kept_idx[o] = -1;
   }
-  // coefficients of the kept anchors, compacted for mask_assemble (detection.py:206)
-  for (int i = t; i < n * (YP_MASK_DIM / 4); i += THREADS) {
-    const int r = i / (YP_MASK_DIM / 4), q = i % (YP_MASK_DIM / 4);
-    const float4 v = reinterpret_cast<const float4*>(p.coef_in + ((size_t)b * p.A + s_anchor[r]) * YP_MASK_DIM)[q];
-    reinterpret_cast<float4*>(p.coef_out + ((size_t)b * p.sel_rows + r) * YP_MASK_DIM)[q] = v;
-  }
   if (t == 0) {
     p.num_det[b] = n;
-    p.stat_surv[b] = p.surv_count[b];
-    p.surv_count[b] = 0;
+    p.stat_surv[b] = survivors;
   }
 }
 
-template <int THREADS, int MODE>
-__global__ __launch_bounds__(THREADS) void segment_nms_kernel(const NmsArgs p) {
-  __shared__ SelectShared sh;
-  __shared__ float4 sbox[YP_SORT_MAX];
-  __shared__ int smax[YP_SORT_MAX];
-  __shared__ int s_anchor[YP_SORT_MAX];
-  __shared__ int s_wave_cnt[YP_SORT_MAX / YP_WAVE];
-  __shared__ int s_base;
-
+// iou_max[j] = max_{i<j} iou(i,j) over the k sorted boxes in sbox; keep = iou_max <= thr, order
+// preserved (detection.py:190-202).  Returns this thread's keep flag (threads < k) and its rank
+// among the kept ones in `pos`; `total` = number kept.  All threads must call it.
+template <int THREADS>
+__device__ bool fast_nms_keep(const float4* sbox, int* smax, int* s_wave_cnt, int k, float thr, int& pos, int& total) {
+  constexpr int G = THREADS / YP_SORT_MAX;
   const int t = threadIdx.x;
-  const int seg = blockIdx.x, b = blockIdx.y;
-  const size_t sidx = (size_t)b * p.nseg + seg;
-  const int n = p.cand_count[sidx];
-  __syncthreads();
-  if (t == 0) p.cand_count[sidx] = 0;   // leave the counter ready for the next run
-  if (n == 0) {
-    if (MODE == YP_NMS_CROSS_CLASS) finish_image<THREADS>(p, b, 0, s_anchor);   // detection.py:81
-    return;
-  }
-  const int k = select_topk_sorted<THREADS>(p.cand + sidx * p.A, n, p.top_k, sh);   // detection.py:186
-
-  if (t < YP_SORT_MAX) {
-    smax[t] = 0;   // +0.0f: the zeroed diagonal/lower triangle take part in reduce_max
-    if (t < k) sbox[t] = p.dec_box[(size_t)b * p.A + yp_seg_key_anchor(sh.key[t])];   // detection.py:187
+  const int j = t % YP_SORT_MAX, g = t / YP_SORT_MAX;
+  if (j < k) {
+    const float4 bj = sbox[j];
+    float mx = 0.0f;   // +0.0f: the zeroed diagonal/lower triangle take part in reduce_max
+    for (int i = g; i < j; i += G) mx = fmaxf(mx, yp_iou(sbox[i], bj));
+    if (G == 1) smax[j] = __float_as_int(mx);
+    else atomicMax(&smax[j], __float_as_int(mx));   // iou >= 0: int order == float order
   }
   __syncthreads();
-
-  // iou_max[j] = max_{i<j} iou(i,j)                                          (detection.py:190-198)
-  {
-    constexpr int G = THREADS / YP_SORT_MAX;
-    const int j = t % YP_SORT_MAX, g = t / YP_SORT_MAX;
-    if (j < k) {
-      const float4 bj = sbox[j];
-      float mx = 0.0f;
-      for (int i = g; i < j; i += G) mx = fmaxf(mx, yp_iou(sbox[i], bj));
-      if (G == 1) smax[j] = __float_as_int(mx);
-      else atomicMax(&smax[j], __float_as_int(mx));   // iou >= 0: int order == float order
-    }
-  }
-  __syncthreads();
-
-  // keep[j] = iou_max[j] <= thr, order preserved                             (detection.py:202)
   bool keep = false;
-  if (t < YP_SORT_MAX && t < k) keep = __int_as_float(smax[t]) <= p.nms_thresh;
-  int pos = 0;
+  if (t < k) keep = __int_as_float(smax[t]) <= thr;
+  pos = 0;
   if (t < YP_SORT_MAX) {
     const u64 ball = __ballot(keep);
     pos = __popcll(ball & ((1ull << (t & 63)) - 1ull));
     if ((t & 63) == 0) s_wave_cnt[t >> 6] = __popcll(ball);
   }
   __syncthreads();
-  int total = 0;
-  if (t < YP_SORT_MAX) {
+  total = 0;
 #pragma unroll
-    for (int w = 0; w < YP_SORT_MAX / YP_WAVE; ++w) {
-      if (w < (t >> 6)) pos += s_wave_cnt[w];
-      total += s_wave_cnt[w];
-    }
+  for (int w = 0; w < YP_SORT_MAX / YP_WAVE; ++w) {
+    if (w < (t >> 6)) pos += s_wave_cnt[w];
+    total += s_wave_cnt[w];
   }
+  return keep;
+}
 
-  if (MODE == YP_NMS_CROSS_CLASS) {
-    if (t >= YP_SORT_MAX) total = 0;
-    // every thread needs `total`
-    if (t == 0) s_base = total;
-    __syncthreads();
-    const int nk = min(s_base, p.max_dets);
-    if (keep && pos < nk) {
-      const u64 key = sh.key[t];
-      const int anchor = yp_seg_key_anchor(key);
-      s_anchor[pos] = anchor;
-      emit_row(p, b, pos, yp_key_score(key), yp_seg_key_class(key), anchor);   // detection.py:204-207
-    }
-    __syncthreads();
-    finish_image<THREADS>(p, b, nk, s_anchor);
-  } else {
-    // class-major pool of survivors for the cross-class top-N               (detection.py:234-239)
-    if (t == 0) s_base = total ? atomicAdd(&p.pool_count[b], total) : 0;
-    __syncthreads();
-    if (keep) {
-      const u64 key = sh.key[t];
-      p.pool[(size_t)b * p.pool_cap + s_base + pos] =
-          yp_fin_key(yp_key_score(key), yp_seg_key_anchor(key), seg + 1);
-    }
+// Cross-class mode: one workgroup per image (detection.py:181-209).
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void cc_nms_kernel(const NmsArgs p) {
+  __shared__ SelectShared sh;
+  __shared__ u64 stage[YP_STAGE_CAP];
+  __shared__ float4 sbox[YP_SORT_MAX];
+  __shared__ int smax[YP_SORT_MAX];
+  __shared__ int s_anchor[YP_SORT_MAX];
+  __shared__ int s_wave_cnt[YP_SORT_MAX / YP_WAVE];
+  const int t = threadIdx.x;
+  const int b = blockIdx.x;
+  const int32_t* counts = p.tile_count + (size_t)b * p.ntiles;
+  int part = 0;
+  for (int i = t; i < p.ntiles; i += THREADS) part += counts[i];
+  const int n = block_sum<THREADS>(part, sh.wtot);            // survivors of the confidence filter
+  if (n == 0) {                                                // detection.py:81
+    finish_image<THREADS>(p, b, 0, s_anchor, 0);
+    return;
   }
+  const SlotSrc src{p.cand + (size_t)b * p.ntiles * p.TA, counts, p.ntiles, p.TA};
+  const int k = select_topk_sorted<THREADS>(src, n, p.top_k, sh, stage);       // detection.py:186
+  float4 mybox = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (t < YP_SORT_MAX) {
+    smax[t] = 0;
+    if (t < k) { mybox = p.dec_box[(size_t)b * p.A + yp_seg_key_anchor(sh.key[t])]; sbox[t] = mybox; }   // L187
+  }
+  __syncthreads();
+  int pos, total;
+  const bool keep = fast_nms_keep<THREADS>(sbox, smax, s_wave_cnt, k, p.nms_thresh, pos, total);
+  const int nk = min(total, p.max_dets);
+  if (keep && pos < nk) {
+    const u64 key = sh.key[t];
+    const int anchor = yp_seg_key_anchor(key);
+    s_anchor[pos] = anchor;
+    emit_row(p, b, pos, yp_key_score(key), yp_seg_key_class(key), anchor, mybox);   // detection.py:204-207
+  }
+  __syncthreads();
+  finish_image<THREADS>(p, b, nk, s_anchor, n);
+}
+
+// Per-class mode: one workgroup per (image, class) (detection.py:217-239).
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void class_nms_kernel(const NmsArgs p) {
+  __shared__ SelectShared sh;
+  __shared__ float4 sbox[YP_SORT_MAX];
+  __shared__ float4 sbox_u[YP_SORT_MAX];
+  __shared__ int smax[YP_SORT_MAX];
+  __shared__ int s_wave_cnt[YP_SORT_MAX / YP_WAVE];
+  const int t = threadIdx.x;
+  const int seg = blockIdx.x, b = blockIdx.y;
+  const size_t sidx = (size_t)b * p.nseg + seg;
+  const u64* list = p.cand + sidx * p.A;
+  // the count and (speculatively) the first 256 keys travel together
+  const int n = p.cand_count[sidx];
+  const u64 kspec = list[min(t, p.A - 1)];
+  __syncthreads();
+  if (t == 0) p.cand_count[sidx] = 0;   // leave the counter ready for the next run
+  if (n == 0) {
+    if (t == 0) p.pool_count[sidx] = 0;
+    return;
+  }
+  int k;
+  if (n <= YP_SORT_MAX) {
+    // boxes are fetched before the sort; the key's class byte (implied by the segment) carries the
+    // slot number so that the sorted order can pick its box up from LDS
+    const bool have = t < n;
+    if (have) sbox_u[t] = p.dec_box[(size_t)b * p.A + yp_seg_key_anchor(kspec)];
+    if (t < YP_SORT_MAX) sh.key[t] = have ? ((kspec & ~0xFFull) | (u64)t) : 0ull;
+    if (t < YP_SORT_MAX) smax[t] = 0;
+    __syncthreads();
+    int sz = 1;
+    while (sz < n) sz <<= 1;
+    for (int k2 = 2; k2 <= sz; k2 <<= 1) {
+      for (int j = k2 >> 1; j > 0; j >>= 1) {
+        if (t < sz) {
+          const int ixj = t ^ j;
+          if (ixj > t) {
+            const u64 x = sh.key[t], y = sh.key[ixj];
+            const bool desc = (t & k2) == 0;
+            if (desc ? (x < y) : (x > y)) { sh.key[t] = y; sh.key[ixj] = x; }
+          }
+        }
+        __syncthreads();
+      }
+    }
+    k = min(p.top_k, n);
+    if (t < k) sbox[t] = sbox_u[(int)(sh.key[t] & 0xFFull)];
+    __syncthreads();
+  } else {
+    const ListSrc ls{list, n};
+    k = select_topk_sorted<THREADS>(ls, n, p.top_k, sh, nullptr);                 // detection.py:217
+    if (t < YP_SORT_MAX) {
+      smax[t] = 0;
+      if (t < k) sbox[t] = p.dec_box[(size_t)b * p.A + yp_seg_key_anchor(sh.key[t])];   // detection.py:219
+    }
+    __syncthreads();
+  }
+  int pos, total;
+  const bool keep = fast_nms_keep<THREADS>(sbox, smax, s_wave_cnt, k, p.nms_thresh, pos, total);
+  // class-major pool of survivors for the cross-class top-N               (detection.py:234-239)
+  if (keep) {
+    const u64 key = sh.key[t];
+    p.pool[sidx * p.top_k + pos] = yp_fin_key(yp_key_score(key), yp_seg_key_anchor(key), seg + 1);
+  }
+  if (t == 0) p.pool_count[sidx] = total;
 }
 
 // Per-class mode only: cross-class top max_dets over the pooled survivors (detection.py:242-248).
 template <int THREADS>
 __global__ __launch_bounds__(THREADS) void final_select_kernel(const NmsArgs p) {
   __shared__ SelectShared sh;
+  __shared__ u64 stage[YP_STAGE_CAP];
   __shared__ int s_anchor[YP_SORT_MAX];
   const int t = threadIdx.x;
   const int b = blockIdx.x;
-  const int n = p.pool_count[b];
-  __syncthreads();
-  if (t == 0) p.pool_count[b] = 0;
+  const int32_t* counts = p.pool_count + (size_t)b * p.nseg;
+  int part = 0;
+  for (int i = t; i < p.nseg; i += THREADS) part += counts[i];
+  const int n = block_sum<THREADS>(part, sh.wtot);
+  part = 0;
+  for (int i = t; i < p.ntiles; i += THREADS) part += p.tile_count[(size_t)b * p.ntiles + i];
+  const int survivors = block_sum<THREADS>(part, sh.wtot);
   int k = 0;
   if (n > 0) {
-    k = select_topk_sorted<THREADS>(p.pool + (size_t)b * p.pool_cap, n, min(p.max_dets, YP_SORT_MAX), sh);
+    const SlotSrc src{p.pool + (size_t)b * p.nseg * p.top_k, counts, p.nseg, p.top_k};
+    k = select_topk_sorted<THREADS>(src, n, min(p.max_dets, YP_SORT_MAX), sh, stage);
     if (t < k) {
       const u64 key = sh.key[t];
       const int anchor = yp_fin_key_anchor(key);
       s_anchor[t] = anchor;
-      emit_row(p, b, t, yp_key_score(key), yp_fin_key_class(key), anchor);
+      emit_row(p, b, t, yp_key_score(key), yp_fin_key_class(key), anchor, p.dec_box[(size_t)b * p.A + anchor]);
     }
     __syncthreads();
   }
-  finish_image<THREADS>(p, b, k, s_anchor);
+  finish_image<THREADS>(p, b, k, s_anchor, survivors);
 }
 
 static NmsArgs make_args(const yp_handle* h, const float* pred_mask_coef, float* det_boxes, float* det_classes,
                          float* det_scores, int32_t* num_det, int32_t* kept_idx) {
   NmsArgs a;
-  a.cand = h->s.cand; a.cand_count = h->s.cand_count; a.surv_count = h->s.surv_count; a.stat_surv = h->s.stat_surv;
+  a.cand = h->s.cand; a.cand_count = h->s.cand_count; a.tile_count = h->s.tile_count; a.stat_surv = h->s.stat_surv;
   a.dec_box = h->s.dec_box; a.pool = h->s.pool; a.pool_count = h->s.pool_count; a.crop = h->s.crop;
   a.coef_out = h->s.coef; a.coef_in = pred_mask_coef;
   a.det_boxes = det_boxes; a.det_classes = det_classes; a.det_scores = det_scores; a.num_det = num_det;
   a.kept_idx = kept_idx;
   a.A = h->cfg.num_anchors; a.nseg = h->nseg; a.top_k = h->cfg.top_k; a.max_dets = h->cfg.max_dets;
-  a.sel_rows = h->sel_rows; a.pool_cap = h->nseg * h->cfg.top_k;
+  a.sel_rows = h->sel_rows; a.ntiles = h->ntiles; a.TA = h->tile_anchors;
   a.nms_thresh = h->cfg.nms_thresh;
   a.img_h = (float)h->cfg.img_h; a.img_w = (float)h->cfg.img_w;
   a.proto_h = (float)h->cfg.proto_h; a.proto_w = (float)h->cfg.proto_w;
@@ -297,9 +421,9 @@ hipError_t yp_launch_segment_nms(const yp_handle* h, int batch, const float* pre
                                  hipStream_t st) {
   const NmsArgs a = make_args(h, pred_mask_coef, det_boxes, det_classes, det_scores, num_det, kept_idx);
   if (h->cfg.nms_mode == YP_NMS_CROSS_CLASS)
-    hipLaunchKernelGGL((segment_nms_kernel<1024, YP_NMS_CROSS_CLASS>), dim3(1, batch), dim3(1024), 0, st, a);
+    hipLaunchKernelGGL((cc_nms_kernel<1024>), dim3(batch), dim3(1024), 0, st, a);
   else
-    hipLaunchKernelGGL((segment_nms_kernel<256, YP_NMS_PER_CLASS>), dim3(h->nseg, batch), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((class_nms_kernel<256>), dim3(h->nseg, batch), dim3(256), 0, st, a);
   return hipGetLastError();
 }
 

@@ -9,65 +9,97 @@
 // streams them with coalesced 16-byte loads into LDS and then works lane-per-anchor on LDS rows
 // (row stride C is odd for C=81 -> conflict-free ds_read_b32).  Offsets and priors are only
 // touched for the few percent of anchors that survive.
+#include <stdlib.h>
 #include "common.hpp"
 
 struct ScoreFilterArgs {
   const float* cls;      // [B,A,C]
   const float* off;      // [B,A,4]
   const float* priors;   // [A,4]
-  u64* cand;             // [B,nseg,A]
-  int32_t* cand_count;   // [B,nseg]
-  int32_t* surv_count;   // [B]
+  u64* cand;             // cross-class: [B, ntiles*TA] tile-major slots; per-class: [B,nseg,A] lists
+  int32_t* cand_count;   // per-class: [B,nseg] list lengths (atomic append)
+  int32_t* tile_count;   // [B,ntiles] survivors of every tile (plain store; doubles as the slot count)
   float4* dec_box;       // [B,A]
-  int A, C, stride, nseg;
+  int A, C, stride, nseg, ntiles;
   float conf, conf_lo;
+  float pre_thresh;      // ln(1/conf - 1) + 1e-3: x_bg - x_fgmax must be below it to have p_fgmax > conf
 };
 
-// One row of tf.nn.softmax's numerator/denominator in YP-MATH order.  On return row[c] holds
-// e_c = exp(x_c - max) for every class and the function yields S = sum_c e_c.
-__device__ __forceinline__ float softmax_row_inplace(float* row, int C) {
-  float m = row[0];
-  for (int c = 1; c < C; ++c) m = fmaxf(m, row[c]);
-  float s[16];
-#pragma unroll
-  for (int j = 0; j < 16; ++j) s[j] = 0.0f;
-  for (int c0 = 0; c0 < C; c0 += 16) {
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      const int c = c0 + j;
-      if (c < C) {
-        const float e = yp_exp(row[c] - m);
-        row[c] = e;
-        s[j] = s[j] + e;
-      }
-    }
-  }
-#pragma unroll
-  for (int w = 8; w >= 1; w >>= 1) {
-#pragma unroll
-    for (int j = 0; j < w; ++j) s[j] = s[j] + s[j + w];
-  }
-  return s[0];
+// ---- cross-lane helpers: DPP moves inside a row of 16 lanes (one VALU op, no LDS round trip) ----
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, false); }
+#define YP_DPP_ROR(n) (0x120 + (n))   // row_ror:n  - lane j reads lane (j+n) mod 16 of its row
+#define YP_DPP_XOR1 0xB1              // quad_perm:[1,0,3,2]
+#define YP_DPP_XOR2 0x4E              // quad_perm:[2,3,0,1]
+
+// YP-MATH tree over the 16 strided partial sums held by a row of 16 lanes: level 1 pairs (j, j+8),
+// level 2 (j, j+4), level 3 (j, j+2), level 4 (j, j+1).  After level k the values are periodic with
+// period 16 >> k, so a rotation by the period pairs exactly those operands (IEEE add commutes) and
+// every lane ends up with the identical total.
+__device__ __forceinline__ float grp16_sum(float v) {
+  v = v + dpp_f<YP_DPP_ROR(8)>(v);
+  v = v + dpp_f<YP_DPP_ROR(4)>(v);
+  v = v + dpp_f<YP_DPP_ROR(2)>(v);
+  v = v + dpp_f<YP_DPP_ROR(1)>(v);
+  return v;
+}
+__device__ __forceinline__ float grp16_max(float v) {
+  v = fmaxf(v, dpp_f<YP_DPP_ROR(8)>(v));
+  v = fmaxf(v, dpp_f<YP_DPP_ROR(4)>(v));
+  v = fmaxf(v, dpp_f<YP_DPP_ROR(2)>(v));
+  v = fmaxf(v, dpp_f<YP_DPP_ROR(1)>(v));
+  return v;
+}
+__device__ __forceinline__ int grp16_min(int v) {
+  v = min(v, dpp_i<YP_DPP_ROR(8)>(v));
+  v = min(v, dpp_i<YP_DPP_ROR(4)>(v));
+  v = min(v, dpp_i<YP_DPP_ROR(2)>(v));
+  v = min(v, dpp_i<YP_DPP_ROR(1)>(v));
+  return v;
 }
 
-template <int MODE>
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void glb_void;
+
+// One wave = one tile of TA consecutive anchors (TA = 16, 32 or 64).
+//   phase 0  the tile's TA*C logits, contiguous in HBM, go straight into LDS with LDS-DMA
+//            (global_load_lds_dwordx4: 1 KiB per wave-instruction, no VGPR staging, all in flight)
+//   phase 1  64/TA lanes per anchor: x_bg, max foreground logit, row max; exact-safe early reject:
+//            p_fgmax <= 1/(1+exp(x_bg-x_fgmax)), so an anchor with x_bg-x_fgmax >= ln(1/conf-1)+1e-3
+//            cannot pass `class_p_max > conf` (detection.py:73) and needs no exponentials at all
+//   phase 2  the remaining anchors, four at a time, 16 lanes per anchor: lane j owns classes
+//            j, j+16, ... - exactly the 16 strided partial sums of the YP-MATH softmax - so the
+//            denominator is a per-lane sequential sum plus one DPP tree (8,4,2,1)
+//   phase 3  survivors: keys appended to the image's candidate list(s), boxes decoded
+template <int MODE, int CPL, int TA>
 __global__ __launch_bounds__(YP_WAVE) void score_filter_kernel(const ScoreFilterArgs p) {
+  constexpr int LPA = YP_WAVE / TA;   // lanes per anchor in phase 1
   extern __shared__ __align__(16) float tile[];
   const int lane = threadIdx.x;
   const int b = blockIdx.y;
-  const int a0 = blockIdx.x * YP_WAVE;
-  const int na = min(YP_WAVE, p.A - a0);
+  const int a0 = blockIdx.x * TA;
+  const int na = min(TA, p.A - a0);
   const int C = p.C;
   const int nelem = na * C;
   const float* __restrict__ src = p.cls + ((size_t)b * p.A + a0) * C;
+  // small per-wave lists behind the tile
+  int* s_list = reinterpret_cast<int*>(tile + TA * p.stride);   // tile-local anchors that passed phase 1
+  int* s_anch = s_list + TA;                                      // tile-local index of survivors
+  u64* s_key = reinterpret_cast<u64*>(s_anch + TA);               // keys waiting to be written out
+  constexpr int KCAP = 128;                                       // capacity of s_key
 
-  // ---- global -> LDS, coalesced -----------------------------------------------------------
+  // ---- phase 0: global -> LDS ------------------------------------------------------------------
   if (p.stride == C && (((uintptr_t)src) & 15u) == 0) {
     const int nvec = nelem >> 2;
     const float4* __restrict__ src4 = reinterpret_cast<const float4*>(src);
-    float4* dst4 = reinterpret_cast<float4*>(tile);
-#pragma unroll 8
-    for (int v = lane; v < nvec; v += YP_WAVE) dst4[v] = src4[v];
+    for (int v0 = 0; v0 < nvec; v0 += YP_WAVE) {
+      if (v0 + lane < nvec)
+        __builtin_amdgcn_global_load_lds((glb_void*)(src4 + v0 + lane), (lds_void*)(tile + 4 * v0), 16, 0, 0);
+    }
     for (int e = (nvec << 2) + lane; e < nelem; e += YP_WAVE) tile[e] = src[e];
   } else {
     for (int e = lane; e < nelem; e += YP_WAVE) {
@@ -75,102 +107,182 @@ __global__ __launch_bounds__(YP_WAVE) void score_filter_kernel(const ScoreFilter
       tile[a * p.stride + (e - a * C)] = src[e];
     }
   }
+  __syncthreads();   // (single wave) waits vmcnt(0): every DMA piece has landed
+
+  // ---- phase 1: LPA lanes per anchor ----------------------------------------------------------
+  const int al1 = lane / LPA, q = lane % LPA;
+  float m;
+  bool pre;
+  {
+    const float* row = tile + min(al1, na - 1) * p.stride;
+    const float x0 = row[0];
+    float xf = -INFINITY;
+    for (int c0 = 1 + q; c0 < C; c0 += 16 * LPA) {
+      float v[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) v[j] = row[min(c0 + LPA * j, C - 1)];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) xf = fmaxf(xf, v[j]);
+    }
+    if (LPA >= 2) xf = fmaxf(xf, dpp_f<YP_DPP_XOR1>(xf));
+    if (LPA >= 4) xf = fmaxf(xf, dpp_f<YP_DPP_XOR2>(xf));
+    m = fmaxf(x0, xf);
+    pre = (al1 < na) && (q == 0) && ((x0 - xf) < p.pre_thresh);
+  }
+  const u64 lt_mask = (1ull << lane) - 1ull;
+  const u64 pm = __ballot(pre);
+  const int npass = __popcll(pm);
+  if (pre) s_list[__popcll(pm & lt_mask)] = al1;
   __syncthreads();
 
-  // ---- lane per anchor ----------------------------------------------------------------------
-  const int a = a0 + lane;
-  bool surv = false;
-  float pmax = 0.0f, emax = 0.0f, S = 1.0f;
-  int arg = 0;
-  float* row = tile + lane * p.stride;
-  if (lane < na) {
-    S = softmax_row_inplace(row, C);
-    emax = row[1];
-    for (int c = 2; c < C; ++c) emax = fmaxf(emax, row[c]);
-    // IEEE division is monotone, so max_c fl(e_c/S) = fl(max_c e_c / S)   (detection.py:62)
-    pmax = emax / S;
-    surv = pmax > p.conf;                                                     // detection.py:73
-  }
-
-  if (MODE == YP_NMS_CROSS_CLASS) {
-    if (surv) {
+  // ---- phase 2: 16 lanes per anchor -----------------------------------------------------------
+  const int grp = lane >> 4, j = lane & 15;
+  int nk = 0;      // survivors so far (wave-uniform)
+  int ncand = 0;   // per-class candidates parked in s_key (wave-uniform)
+  for (int t0 = 0; t0 < npass; t0 += 4) {
+    const int slot = t0 + grp;
+    const bool act = slot < npass;
+    const int al = act ? s_list[slot] : 0;
+    const float ma = __shfl(m, al * LPA);
+    const float* r = tile + al * p.stride;
+    float e[CPL];
+    float s = 0.0f, em = 0.0f;
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) {
+      const int c = j + 16 * i;
+      const bool ok = c < C;
+      const float x = r[ok ? c : 0];
+      e[i] = ok ? yp_exp(x - ma) : 0.0f;
+      s = s + e[i];                                        // s_j = e_j + e_{j+16} + ...
+      if (i > 0) em = fmaxf(em, e[i]);
+      else if (j > 0) em = e[0];                           // class 0 is background (detection.py:59)
+    }
+    const float S = grp16_sum(s);
+    em = grp16_max(em);
+    // IEEE division is monotone, so max_c fl(e_c/S) = fl(max_c e_c / S)                (detection.py:62)
+    const float pmax = em / S;
+    const bool surv = act && (pmax > p.conf);                                        // detection.py:73
+    const bool lead = surv && j == 0;
+    const u64 bl = __ballot(lead);
+    const int pos = nk + __popcll(bl & lt_mask);
+    if (MODE == YP_NMS_CROSS_CLASS) {
       // tf.argmax over the probabilities (detection.py:184): the FIRST class whose rounded
       // probability equals the maximum.  Only an e_c within 2^-21 of the largest can round to it.
-      const float ethr = emax * (1.0f - 0x1p-21f);
-      for (int c = 1; c < C; ++c) {
-        const float e = row[c];
-        if (arg == 0 && e >= ethr) {
-          if (e / S == pmax) arg = c;
-        }
-      }
-    }
-    const u64 ball = __ballot(surv);
-    if (ball) {
-      int base = 0;
-      const int leader = __ffsll((long long)ball) - 1;
-      if (lane == leader) base = atomicAdd(&p.cand_count[b], __popcll(ball));
-      base = __shfl(base, leader);
+      int arg = 0x7fffffff;
       if (surv) {
-        const int pos = base + __popcll(ball & ((1ull << lane) - 1ull));
-        p.cand[(size_t)b * p.A + pos] = yp_seg_key(pmax, a, arg);
-      }
-    }
-  } else {
-    // per-class candidates: every (anchor, class) with p > conf                (detection.py:233)
-    if (__ballot(surv)) {
-      const float elo = S * p.conf_lo;
-      for (int c = 1; c < C; ++c) {
-        const float e = row[c];
-        if (surv && e >= elo) {
-          const float pc = e / S;
-          if (pc > p.conf) {
-            const size_t seg = (size_t)b * p.nseg + (c - 1);
-            const int pos = atomicAdd(&p.cand_count[seg], 1);
-            p.cand[seg * p.A + pos] = yp_seg_key(pc, a, c);
+        const float ethr = em * (1.0f - 0x1p-21f);
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) {
+          const int c = j + 16 * i;
+          if (c >= 1 && c < C && e[i] >= ethr) {
+            if (e[i] / S == pmax) arg = min(arg, c);
           }
         }
       }
+      arg = grp16_min(arg);
+      if (lead) {
+        s_anch[pos] = al;
+        s_key[pos] = yp_seg_key(pmax, a0 + al, arg);
+      }
+    } else {
+      // per-class candidates: every (anchor, class) with p > conf                   (detection.py:233)
+      // They are parked in LDS and appended to the per-class lists 64 at a time, so that the
+      // returning atomics of a whole tile are in flight together instead of one after another.
+      const float elo = S * p.conf_lo;
+#pragma unroll
+      for (int i = 0; i < CPL; ++i) {
+        const int c = j + 16 * i;
+        bool has = false;
+        float pc = 0.0f;
+        if (surv && c >= 1 && c < C && e[i] >= elo) {
+          pc = e[i] / S;
+          has = pc > p.conf;
+        }
+        const u64 bm = __ballot(has);
+        if (bm) {
+          if (has) s_key[ncand + __popcll(bm & lt_mask)] = yp_seg_key(pc, a0 + al, c);
+          ncand += __popcll(bm);
+          if (ncand > KCAP - YP_WAVE) {   // wave-uniform
+            __syncthreads();
+            for (int l = lane; l < ncand; l += YP_WAVE) {
+              const u64 key = s_key[l];
+              const size_t seg = (size_t)b * p.nseg + (yp_seg_key_class(key) - 1);
+              const int qpos = atomicAdd(&p.cand_count[seg], 1);
+              p.cand[seg * p.A + qpos] = key;
+            }
+            __syncthreads();
+            ncand = 0;
+          }
+        }
+      }
+      if (lead) s_anch[pos] = al;
     }
+    nk += __popcll(bl);
   }
+  if (lane == 0) p.tile_count[(size_t)b * p.ntiles + blockIdx.x] = nk;
+  if (nk == 0) return;
+  __syncthreads();
 
-  // ---- decode the survivors (utils/utils.py:193-213) ---------------------------------------
-  const u64 sball = __ballot(surv);
-  if (sball) {
-    if (lane == __ffsll((long long)sball) - 1) atomicAdd(&p.surv_count[b], __popcll(sball));
-    if (surv) {
-      const float4 pr = reinterpret_cast<const float4*>(p.priors)[a];                       // y0,x0,y1,x1
-      const float4 of = reinterpret_cast<const float4*>(p.off)[(size_t)b * p.A + a];        // dx,dy,dw,dh
-      const float ph = pr.z - pr.x;
-      const float pw = pr.w - pr.y;
-      const float cx = pr.y + (pw / 2.0f);
-      const float cy = pr.x + (ph / 2.0f);
-      const float bx = cx + (of.x * pw) * 0.1f;
-      const float by = cy + (of.y * ph) * 0.1f;
-      const float bw = pw * yp_exp(of.z * 0.2f);
-      const float bh = ph * yp_exp(of.w * 0.2f);
-      float4 box;
-      box.y = bx - bw / 2.0f;   // xmin
-      box.x = by - bh / 2.0f;   // ymin
-      box.w = bw / 2.0f + bx;   // xmax
-      box.z = bh / 2.0f + by;   // ymax
-      p.dec_box[(size_t)b * p.A + a] = box;
+  // ---- phase 3: survivors ---------------------------------------------------------------------
+  if (MODE == YP_NMS_CROSS_CLASS) {
+    if (lane < nk) p.cand[((size_t)b * p.ntiles + blockIdx.x) * TA + lane] = s_key[lane];
+  } else {
+    for (int l = lane; l < ncand; l += YP_WAVE) {
+      const u64 key = s_key[l];
+      const size_t seg = (size_t)b * p.nseg + (yp_seg_key_class(key) - 1);
+      const int qpos = atomicAdd(&p.cand_count[seg], 1);
+      p.cand[seg * p.A + qpos] = key;
     }
   }
+  if (lane < nk) {   // utils._decode, utils/utils.py:193-213
+    const int a = a0 + s_anch[lane];
+    const float4 pr = reinterpret_cast<const float4*>(p.priors)[a];                       // y0,x0,y1,x1
+    const float4 of = reinterpret_cast<const float4*>(p.off)[(size_t)b * p.A + a];        // dx,dy,dw,dh
+    const float ph = pr.z - pr.x;
+    const float pw = pr.w - pr.y;
+    const float cx = pr.y + (pw / 2.0f);
+    const float cy = pr.x + (ph / 2.0f);
+    const float bx = cx + (of.x * pw) * 0.1f;
+    const float by = cy + (of.y * ph) * 0.1f;
+    const float bw = pw * yp_exp(of.z * 0.2f);
+    const float bh = ph * yp_exp(of.w * 0.2f);
+    float4 box;
+    box.y = bx - bw / 2.0f;   // xmin
+    box.x = by - bh / 2.0f;   // ymin
+    box.w = bw / 2.0f + bx;   // xmax
+    box.z = bh / 2.0f + by;   // ymax
+    p.dec_box[(size_t)b * p.A + a] = box;
+  }
+}
+
+template <int MODE, int TA>
+static void launch_mode(int cpl, int A, int batch, size_t lds, hipStream_t st, const ScoreFilterArgs& a) {
+  const dim3 grid((A + TA - 1) / TA, batch);
+#define YP_SF_CASE(N) case N: hipLaunchKernelGGL((score_filter_kernel<MODE, N, TA>), grid, dim3(YP_WAVE), lds, st, a); break;
+  switch (cpl) {
+    YP_SF_CASE(1) YP_SF_CASE(2) YP_SF_CASE(3) YP_SF_CASE(4) YP_SF_CASE(5) YP_SF_CASE(6)
+    YP_SF_CASE(8) YP_SF_CASE(12) YP_SF_CASE(16)
+  }
+#undef YP_SF_CASE
 }
 
 hipError_t yp_launch_score_filter(const yp_handle* h, int batch, const float* pred_cls, const float* pred_offset,
                                   const float* priors, hipStream_t st) {
   ScoreFilterArgs a;
   a.cls = pred_cls; a.off = pred_offset; a.priors = priors;
-  a.cand = h->s.cand; a.cand_count = h->s.cand_count; a.surv_count = h->s.surv_count; a.dec_box = h->s.dec_box;
+  a.cand = h->s.cand; a.cand_count = h->s.cand_count; a.tile_count = h->s.tile_count; a.dec_box = h->s.dec_box;
   a.A = h->cfg.num_anchors; a.C = h->cfg.num_classes; a.stride = h->lds_stride; a.nseg = h->nseg;
   a.conf = h->cfg.conf_thresh;
   a.conf_lo = h->cfg.conf_thresh * (1.0f - 0x1p-20f);
-  const dim3 grid((a.A + YP_WAVE - 1) / YP_WAVE, batch);
-  const size_t lds = (size_t)YP_WAVE * a.stride * sizeof(float);
-  if (h->cfg.nms_mode == YP_NMS_CROSS_CLASS)
-    hipLaunchKernelGGL(score_filter_kernel<YP_NMS_CROSS_CLASS>, grid, dim3(YP_WAVE), lds, st, a);
-  else
-    hipLaunchKernelGGL(score_filter_kernel<YP_NMS_PER_CLASS>, grid, dim3(YP_WAVE), lds, st, a);
+  a.pre_thresh = h->pre_thresh;
+  const int TA = h->tile_anchors;
+  a.ntiles = h->ntiles;
+  const size_t lds = (size_t)TA * a.stride * sizeof(float) + TA * 2 * sizeof(int) + 128 * sizeof(u64);
+  int cpl = (a.C + 15) / 16;                       // classes per lane in phase 2
+  if (cpl == 7) cpl = 8; else if (cpl > 8 && cpl <= 12) cpl = 12; else if (cpl > 12) cpl = 16;
+  const bool cc = h->cfg.nms_mode == YP_NMS_CROSS_CLASS;
+  if (TA == 64) { if (cc) launch_mode<YP_NMS_CROSS_CLASS, 64>(cpl, a.A, batch, lds, st, a); else launch_mode<YP_NMS_PER_CLASS, 64>(cpl, a.A, batch, lds, st, a); }
+  else if (TA == 32) { if (cc) launch_mode<YP_NMS_CROSS_CLASS, 32>(cpl, a.A, batch, lds, st, a); else launch_mode<YP_NMS_PER_CLASS, 32>(cpl, a.A, batch, lds, st, a); }
+  else { if (cc) launch_mode<YP_NMS_CROSS_CLASS, 16>(cpl, a.A, batch, lds, st, a); else launch_mode<YP_NMS_PER_CLASS, 16>(cpl, a.A, batch, lds, st, a); }
   return hipGetLastError();
 }
