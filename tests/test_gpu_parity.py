@@ -1,0 +1,235 @@
+"""Parity of the HIP path (through the C ABI) against the oracle, on a real MI355X.
+
+Bars (BASELINE.json north_star): kept anchor indices, classes and NMS ordering bit-exact; boxes,
+scores and masks within 1e-5 abs.  Against the C oracle (same YP-MATH arithmetic contract) the test
+is stricter: every output float must be bit-identical.  Against the independent numpy oracle
+(libm exp, numpy reductions, BLAS matmul) the 1e-5 tolerance applies and indices must be exact on
+the committed golden fixtures."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from tests.util import compare, to_numpy
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+TOL = 1e-5   # north_star tolerance for boxes / scores / masks
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return torch
+
+
+def run_gpu(torch, net, shp, *, mode, top_k, max_dets, conf=0.05, nms=0.5, use_crop=True, zero_pad=False,
+            mask_threshold=-1.0, max_batch=None):
+    from yolact_amd import PostConfig, PostProcessor
+    B, A, C = net["pred_cls"].shape
+    ph, pw = net["proto_out"].shape[1:3]
+    pp = PostProcessor(PostConfig(A, C, ph, pw, int(shp[1]), int(shp[2]), conf_thresh=conf, nms_thresh=nms,
+                                  nms_mode=mode, top_k=top_k, max_dets=max_dets, use_cropped_mask=use_crop,
+                                  zero_pad_masks=zero_pad, mask_threshold=mask_threshold, max_batch=max_batch or B))
+    dev = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in net.items()}
+    out = pp.run(dev["pred_offset"], dev["pred_cls"], dev["pred_mask_coef"], dev["priors"], dev["proto_out"])
+    pp.sync()
+    got = to_numpy(out)
+    got["num_survivors"] = pp.last_survivors(B)
+    pp.close()
+    return got
+
+
+def check_vs_c_oracle(torch, net, shp, *, mode, top_k, max_dets, conf=0.05, nms=0.5, use_crop=True, nthreads=8, label=""):
+    from oracle import c_oracle as co
+    got = run_gpu(torch, net, shp, mode=mode, top_k=top_k, max_dets=max_dets, conf=conf, nms=nms, use_crop=use_crop)
+    ref = co.detect(net, shp, conf_thresh=conf, nms_thresh=nms, top_k=top_k, nms_mode=mode, max_dets=max_dets,
+                    use_cropped_mask=use_crop, nthreads=nthreads)
+    assert np.array_equal(got["num_survivors"], ref["num_survivors"]), label
+    compare(got, ref, exact_values=True, label=label)
+    return got, ref
+
+
+MODES = [("cc", 15, 15), ("cc", 200, 100), ("per_class", 200, 100), ("per_class", 15, 7), ("cc", 256, 300)]
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+@pytest.mark.parametrize("mode,top_k,max_dets", MODES)
+def test_toy_bit_exact_vs_c_oracle(torch_cuda, seed, mode, top_k, max_dets):
+    from yolact_amd import synth
+    if mode == "per_class" and max_dets > 256:
+        pytest.skip("per-class rows <= 256")
+    net, shp = synth.make_toy(seed)            # A = 240: ragged last tile, S < top_k for some settings
+    check_vs_c_oracle(torch_cuda, net, shp, mode=mode, top_k=top_k, max_dets=max_dets, label=f"toy{seed}")
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "toy_*.npz"))))
+def test_golden_fixtures_vs_numpy_oracle_outputs(torch_cuda, path):
+    """Committed vectors made by the independent numpy oracle: indices exact, values within 1e-5."""
+    z = np.load(path)
+    net = {k[3:]: z[k] for k in z.files if k.startswith("in_")}
+    got = run_gpu(torch_cuda, net, z["img_shape"], mode=str(z["nms_mode"]), top_k=int(z["top_k"]),
+                  max_dets=int(z["max_dets"]), conf=float(z["conf"]))
+    ref = {k[4:]: z[k] for k in z.files if k.startswith("out_")}
+    assert np.array_equal(got["num_survivors"], ref["num_survivors"])
+    compare(got, ref, exact_values=False, atol=TOL, label=os.path.basename(path))
+
+
+def test_golden_config2_image0(torch_cuda):
+    from yolact_amd import synth
+    z = np.load(os.path.join(GOLDEN, "config2_image0.npz"))
+    cfg = synth.CONFIGS[2]
+    net, shp = synth.make_batch(cfg, batch=1)
+    for mode, top_k, max_dets in (("cc", 15, 15), ("cc", 200, 100), ("per_class", 200, 100)):
+        tag = f"{mode}_{top_k}"
+        got = run_gpu(torch_cuda, net, shp, mode=mode, top_k=top_k, max_dets=max_dets, conf=cfg.conf_thresh)
+        for k in ("num_detections", "num_survivors", "detection_anchor_indices", "detection_classes"):
+            assert np.array_equal(got[k], z[f"{tag}_{k}"]), (tag, k)
+        for k in ("detection_scores", "detection_boxes"):
+            assert np.abs(got[k] - z[f"{tag}_{k}"]).max() <= TOL, (tag, k)
+        m = got["detection_masks"][0].reshape(max_dets, -1)
+        assert np.abs(m.sum(axis=1, dtype=np.float64) - z[f"{tag}_mask_sums"]).max() < 1e-2
+        assert np.array_equal((m > 0).sum(axis=1), z[f"{tag}_mask_nonzero"])
+
+
+@pytest.mark.parametrize("mode,top_k,max_dets", [("cc", 15, 15), ("cc", 200, 100), ("per_class", 200, 100)])
+def test_config2_batch8_bit_exact(torch_cuda, mode, top_k, max_dets):
+    from yolact_amd import synth
+    cfg = synth.CONFIGS[2]
+    net, shp = synth.make_batch(cfg, batch=8)
+    check_vs_c_oracle(torch_cuda, net, shp, mode=mode, top_k=top_k, max_dets=max_dets, conf=cfg.conf_thresh, label="cfg2")
+
+
+def test_config1_random_init_has_no_survivors(torch_cuda):
+    """BASELINE config 1 with random-init-like logits: max fg prob ~ 1/81 < conf -> empty image (detection.py:81)."""
+    from yolact_amd import synth
+    cfg = synth.CONFIGS[1]
+    net, shp = synth.make_batch(cfg, batch=1, mode="random_init")
+    got, _ = check_vs_c_oracle(torch_cuda, net, shp, mode="cc", top_k=15, max_dets=15, label="cfg1-empty")
+    assert got["num_detections"][0] == 0 and got["num_survivors"][0] == 0
+    assert not got["detection_scores"].any() and (got["detection_anchor_indices"] == -1).all()
+    net, shp = synth.make_batch(cfg, batch=1, mode="planted")
+    check_vs_c_oracle(torch_cuda, net, shp, mode="cc", top_k=15, max_dets=15, label="cfg1-planted")
+
+
+@pytest.mark.parametrize("mode", ["per_class", "cc"])
+def test_config4_nms_stress_bit_exact(torch_cuda, mode):
+    """conf 0.01, every anchor planted: saturated top-200 in all 80 classes; in cc mode the image holds
+    19248 candidates, which exercises the un-staged radix select."""
+    from yolact_amd import synth
+    cfg = synth.CONFIGS[4]
+    net, shp = synth.make_batch(cfg, batch=2)
+    got, ref = check_vs_c_oracle(torch_cuda, net, shp, mode=mode, top_k=200, max_dets=100, conf=cfg.conf_thresh, label="cfg4")
+    assert (ref["num_survivors"] > 19000).all()
+
+
+@pytest.mark.parametrize("cfg_id", [3, 5])
+def test_non_square_configs_bit_exact(torch_cuda, cfg_id):
+    from yolact_amd import synth
+    cfg = synth.CONFIGS[cfg_id]
+    net, shp = synth.make_batch(cfg, batch=2)
+    check_vs_c_oracle(torch_cuda, net, shp, mode="per_class", top_k=200, max_dets=100, label=f"cfg{cfg_id}")
+    check_vs_c_oracle(torch_cuda, net, shp, mode="cc", top_k=15, max_dets=15, label=f"cfg{cfg_id}")
+
+
+@pytest.mark.parametrize("num_classes", [2, 4, 17, 33, 100, 130, 256])
+def test_class_counts_even_and_odd(torch_cuda, num_classes):
+    """Even C takes the padded-stride LDS path; C > 96 the wider per-lane class loops."""
+    from yolact_amd import synth
+    net, shp = synth.make_toy(9, num_classes=num_classes)
+    check_vs_c_oracle(torch_cuda, net, shp, mode="cc", top_k=30, max_dets=30, label=f"C{num_classes}")
+    check_vs_c_oracle(torch_cuda, net, shp, mode="per_class", top_k=30, max_dets=30, label=f"C{num_classes}")
+
+
+def test_thresholds_and_options(torch_cuda):
+    from yolact_amd import synth
+    from oracle import c_oracle as co
+    net, shp = synth.make_toy(4)
+    check_vs_c_oracle(torch_cuda, net, shp, mode="cc", top_k=100, max_dets=100, conf=0.6, nms=0.3, label="conf.6")
+    check_vs_c_oracle(torch_cuda, net, shp, mode="cc", top_k=100, max_dets=100, conf=0.999999, label="S=0")
+    check_vs_c_oracle(torch_cuda, net, shp, mode="per_class", top_k=100, max_dets=5, conf=0.01, nms=0.9, label="truncate")
+    check_vs_c_oracle(torch_cuda, net, shp, mode="cc", top_k=50, max_dets=50, use_crop=False, label="nocrop")
+    # zero padding of unused mask rows + thresholded bitmaps
+    got = run_gpu(torch_cuda, net, shp, mode="cc", top_k=15, max_dets=40, zero_pad=True, mask_threshold=0.5)
+    ref = co.detect(net, shp, top_k=15, nms_mode="cc", max_dets=40)
+    compare(got, ref, exact_values=True, label="zero_pad")
+    for b in range(2):
+        n = int(ref["num_detections"][b])
+        assert not got["detection_masks"][b, n:].any()
+        assert np.array_equal(got["detection_bitmaps"][b, :n], (ref["detection_masks"][b, :n] > 0.5).astype(np.uint8))
+        assert not got["detection_bitmaps"][b, n:].any()
+
+
+def test_handle_reuse_and_smaller_batches(torch_cuda):
+    """One handle, several runs with different batch sizes: scratch counters are left clean between runs."""
+    from yolact_amd import PostConfig, PostProcessor, synth
+    from oracle import c_oracle as co
+    torch = torch_cuda
+    net, shp = synth.make_toy(6, batch=5)
+    B, A, C = net["pred_cls"].shape
+    for mode in ("cc", "per_class"):
+        pp = PostProcessor(PostConfig(A, C, 12, 12, 64, 64, nms_mode=mode, top_k=40, max_dets=20, max_batch=5))
+        for nb in (5, 2, 5, 1):
+            sub = {k: (v if k == "priors" else v[:nb]) for k, v in net.items()}
+            dev = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in sub.items()}
+            out = pp.run(dev["pred_offset"], dev["pred_cls"], dev["pred_mask_coef"], dev["priors"], dev["proto_out"])
+            pp.sync()
+            ref = co.detect(sub, shp, top_k=40, nms_mode=mode, max_dets=20)
+            compare(to_numpy(out), ref, exact_values=True, label=f"reuse-{mode}-{nb}")
+        with pytest.raises(Exception, match="max_batch"):
+            big = {k: torch.from_numpy(np.ascontiguousarray(np.concatenate([v, v]) if k != "priors" else v)).cuda() for k, v in net.items()}
+            pp.run(big["pred_offset"], big["pred_cls"], big["pred_mask_coef"], big["priors"], big["proto_out"])
+        pp.close()
+
+
+def test_detect_wrapper_reference_layout(torch_cuda):
+    """Drop-in class, reference defaults: cross-class, top_k 15, 300 zero-padded rows (detection.py:21,65-69)."""
+    from yolact_amd import Detect, synth
+    from oracle import detect_oracle as po
+    net, shp = synth.make_toy(8)
+    det = Detect(5, max_output_size=17, per_class_max_output_size=3, conf_thresh=0.05, nms_thresh=0.5)
+    res = to_numpy(det(net, shp))
+    ref = po.detect(net, shp, conf_thresh=0.05, top_k=15, nms_mode="cc", max_output_size=300)
+    assert res["detection_masks"].shape == (2, 300, 12, 12) and res["detection_boxes"].shape == (2, 300, 4)
+    assert res["num_detections"].dtype == np.int32 and res["detection_classes"].dtype == np.float32
+    compare(res, ref, exact_values=False, atol=TOL, label="Detect")
+    for b in range(2):
+        assert not res["detection_masks"][b, int(ref["num_detections"][b]):].any()      # tf.zeros rows
+    # unlocked knobs
+    det2 = Detect(5, 100, 100, 0.05, 0.4, strict_reference=False, nms_mode="per_class", top_k=200, max_dets=100)
+    res2 = to_numpy(det2(net, shp))
+    ref2 = po.detect(net, shp, conf_thresh=0.05, nms_thresh=0.4, top_k=200, nms_mode="per_class", max_output_size=100, max_dets=100)
+    compare(res2, ref2, exact_values=False, atol=TOL, label="Detect-per-class")
+
+
+def test_full_size_batch32_properties_and_oracle(torch_cuda):
+    """BASELINE config 2 at its full size (batch 32): bit-exact against the C oracle, plus the
+    size-independent properties of the path: idempotence, image-permutation equivariance,
+    descending scores, masks in [0,1] and zero outside the padded crop box."""
+    from yolact_amd import synth
+    cfg = synth.CONFIGS[2]
+    net, shp = synth.make_batch(cfg, batch=32)
+    got, ref = check_vs_c_oracle(torch_cuda, net, shp, mode="per_class", top_k=200, max_dets=100, conf=cfg.conf_thresh, label="cfg2-b32")
+    again = run_gpu(torch_cuda, net, shp, mode="per_class", top_k=200, max_dets=100)
+    for k in ("detection_boxes", "detection_scores", "detection_classes", "detection_anchor_indices", "detection_masks"):
+        assert np.array_equal(got[k], again[k]), "not idempotent: " + k
+    perm = np.random.default_rng(0).permutation(32)
+    pnet = {k: (v if k == "priors" else v[perm]) for k, v in net.items()}
+    pgot = run_gpu(torch_cuda, pnet, shp, mode="per_class", top_k=200, max_dets=100)
+    for k in ("detection_boxes", "detection_scores", "detection_classes", "detection_anchor_indices", "num_detections"):
+        assert np.array_equal(pgot[k], got[k][perm]), "not permutation equivariant: " + k
+    for b in range(32):
+        n = int(got["num_detections"][b])
+        s = got["detection_scores"][b, :n]
+        assert n <= 100 and np.all(s[:-1] >= s[1:]) and np.all(s > cfg.conf_thresh)
+        m = got["detection_masks"][b, :n]
+        assert m.min() >= 0.0 and m.max() <= 1.0
+        bx = got["detection_boxes"][b, :n]
+        y1 = np.clip(np.minimum(bx[:, 0], bx[:, 2]) * 138 - 1, 0, 138); y2 = np.clip(np.maximum(bx[:, 0], bx[:, 2]) * 138 + 1, 0, 138)
+        for i in range(0, n, 17):
+            rows_out = np.r_[0:int(np.floor(y1[i]))]
+            assert not m[i, rows_out].any()
+            assert not m[i, int(np.ceil(y2[i])) + 1:].any()

@@ -79,7 +79,6 @@ extern "C" int yp_create(const yp_config* cfg, yp_handle** out) {
   const size_t pool_per_img = per_class ? nseg * (size_t)c.top_k : 0;
   size_t off = 0;
   const size_t o_cand = off;  off = align_up(off + B * cand_per_img * sizeof(u64), 256);
-  const size_t o_box = off;   off = align_up(off + B * A * sizeof(float4), 256);
   const size_t o_pool = off;  off = align_up(off + B * pool_per_img * sizeof(u64), 256);
   const size_t o_crop = off;  off = align_up(off + B * h->sel_rows * sizeof(float4), 256);
   const size_t o_coef = off;  off = align_up(off + B * h->sel_rows * YP_MASK_DIM * sizeof(float), 256);
@@ -93,7 +92,6 @@ extern "C" int yp_create(const yp_config* cfg, yp_handle** out) {
   }
   char* base = (char*)h->scratch_base;
   h->s.cand = (u64*)(base + o_cand);
-  h->s.dec_box = (float4*)(base + o_box);
   h->s.pool = (u64*)(base + o_pool);
   h->s.crop = (float4*)(base + o_crop);
   h->s.coef = (float*)(base + o_coef);
@@ -142,12 +140,12 @@ extern "C" int yp_run(yp_handle* h, int32_t batch, const float* pred_offset, con
   h->last_batch = batch;
   const bool prof = h->profile != 0;
   if (prof) YP_HIP(hipEventRecord(h->ev[0], st));
-  YP_HIP(yp_launch_score_filter(h, batch, pred_cls, pred_offset, priors, st));
+  YP_HIP(yp_launch_score_filter(h, batch, pred_cls, st));
   if (prof) YP_HIP(hipEventRecord(h->ev[1], st));
-  YP_HIP(yp_launch_segment_nms(h, batch, pred_mask_coef, det_boxes, det_classes, det_scores, num_det, kept_anchor_idx, st));
+  YP_HIP(yp_launch_segment_nms(h, batch, pred_offset, priors, pred_mask_coef, det_boxes, det_classes, det_scores, num_det, kept_anchor_idx, st));
   if (prof) YP_HIP(hipEventRecord(h->ev[2], st));
   if (h->cfg.nms_mode == YP_NMS_PER_CLASS)
-    YP_HIP(yp_launch_final_select(h, batch, pred_mask_coef, det_boxes, det_classes, det_scores, num_det, kept_anchor_idx, st));
+    YP_HIP(yp_launch_final_select(h, batch, pred_offset, priors, pred_mask_coef, det_boxes, det_classes, det_scores, num_det, kept_anchor_idx, st));
   if (prof) YP_HIP(hipEventRecord(h->ev[3], st));
   if (det_masks) YP_HIP(yp_launch_mask_assemble(h, batch, proto, num_det, det_masks, det_bitmaps, st));
   if (prof) YP_HIP(hipEventRecord(h->ev[4], st));

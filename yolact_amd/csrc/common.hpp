@@ -40,8 +40,10 @@ __host__ __device__ inline int yp_fin_key_class(u64 k) { return (int)(255u - (ui
 
 #ifdef __HIPCC__
 // ---- YP-MATH device functions -------------------------------------------------------------
-__device__ __forceinline__ float yp_exp(float x) {
-  x = fminf(fmaxf(x, -87.0f), 87.0f);
+template <bool NONPOS>
+__device__ __forceinline__ float yp_exp_t(float x) {
+  x = fmaxf(x, -87.0f);
+  if (!NONPOS) x = fminf(x, 87.0f);   // a no-op for x <= 0 (softmax arguments), so it is skipped there
   const float fx = floorf(__builtin_fmaf(x, 1.44269504088896341f, 0.5f));
   float r = __builtin_fmaf(fx, -0.693359375f, x);
   r = __builtin_fmaf(fx, 2.12194440e-4f, r);
@@ -58,6 +60,9 @@ __device__ __forceinline__ float yp_exp(float x) {
   return y * __builtin_bit_cast(float, (uint32_t)(n + 127) << 23);
 }
 
+__device__ __forceinline__ float yp_exp(float x) { return yp_exp_t<false>(x); }
+__device__ __forceinline__ float yp_exp_le0(float x) { return yp_exp_t<true>(x); }   // caller guarantees x <= 0
+
 __device__ __forceinline__ float yp_sigmoid(float x) { return 1.0f / (1.0f + yp_exp(-x)); }
 
 __device__ __forceinline__ float yp_clip(float t, float lo, float hi) { return fminf(fmaxf(t, lo), hi); }
@@ -71,6 +76,25 @@ __device__ __forceinline__ float yp_iou(const float4 a, const float4 b) {
   const float inter = ih * iw;
   const float uni = (area1 + area2) - inter;
   return inter == 0.0f ? 0.0f : inter / uni;
+}
+
+// utils._decode for one anchor (utils/utils.py:193-213).  pr = prior (ymin,xmin,ymax,xmax) pixels,
+// of = (dx,dy,dw,dh); returns the box as (ymin,xmin,ymax,xmax) pixels.
+__device__ __forceinline__ float4 yp_decode(const float4 pr, const float4 of) {
+  const float ph = pr.z - pr.x;                    // L193
+  const float pw = pr.w - pr.y;                    // L194
+  const float cx = pr.y + (pw / 2.0f);             // L196
+  const float cy = pr.x + (ph / 2.0f);             // L197
+  const float bx = cx + (of.x * pw) * 0.1f;        // L201
+  const float by = cy + (of.y * ph) * 0.1f;
+  const float bw = pw * yp_exp(of.z * 0.2f);       // L202
+  const float bh = ph * yp_exp(of.w * 0.2f);
+  float4 box;
+  box.y = bx - bw / 2.0f;   // xmin                   L210
+  box.x = by - bh / 2.0f;   // ymin
+  box.w = bw / 2.0f + bx;   // xmax
+  box.z = bh / 2.0f + by;   // ymax
+  return box;                                      // L213
 }
 
 // utils.sanitize_coordinates (utils/utils.py:89-104).
@@ -91,7 +115,6 @@ struct yp_scratch {
   int32_t* cand_count;  // per-class: [max_batch][nseg] list lengths (zero between runs: class_nms resets)
   int32_t* tile_count;  // [max_batch][ntiles] survivors per score_filter tile (rewritten every run)
   int32_t* stat_surv;   // [max_batch] anchors past the confidence filter, for yp_last_survivors
-  float4* dec_box;      // [max_batch][A] decoded boxes, written at survivor anchors only
   u64* pool;            // [max_batch][nseg][top_k] per-class NMS survivors (per-class mode)
   int32_t* pool_count;  // [max_batch][nseg] (rewritten every run)
   float4* crop;         // [max_batch][sel_rows] (x1,x2,y1,y2) crop edges in proto pixels
@@ -116,12 +139,13 @@ struct yp_handle {
 };
 
 // Kernel launchers (one per translation unit).  All asynchronous on `st`.
-hipError_t yp_launch_score_filter(const yp_handle* h, int batch, const float* pred_cls, const float* pred_offset,
-                                  const float* priors, hipStream_t st);
-hipError_t yp_launch_segment_nms(const yp_handle* h, int batch, const float* pred_mask_coef, float* det_boxes,
+hipError_t yp_launch_score_filter(const yp_handle* h, int batch, const float* pred_cls, hipStream_t st);
+hipError_t yp_launch_segment_nms(const yp_handle* h, int batch, const float* pred_offset, const float* priors,
+                                 const float* pred_mask_coef, float* det_boxes,
                                  float* det_classes, float* det_scores, int32_t* num_det, int32_t* kept_idx,
                                  hipStream_t st);
-hipError_t yp_launch_final_select(const yp_handle* h, int batch, const float* pred_mask_coef, float* det_boxes,
+hipError_t yp_launch_final_select(const yp_handle* h, int batch, const float* pred_offset, const float* priors,
+                                  const float* pred_mask_coef, float* det_boxes,
                                   float* det_classes, float* det_scores, int32_t* num_det, int32_t* kept_idx,
                                   hipStream_t st);
 hipError_t yp_launch_mask_assemble(const yp_handle* h, int batch, const float* proto, const int32_t* num_det,

@@ -11,6 +11,7 @@
 // come in through scalar loads.  The dot product is a K-ordered fma chain (YP-MATH) and is skipped
 // for waves whose 64*PPL pixels lie entirely outside detection n's crop box - those only store
 // zeros.  Output is written [N][P] (pixel-contiguous), which is the reference's final layout.
+#include <stdlib.h>
 #include "common.hpp"
 
 struct MaskArgs {
@@ -65,9 +66,16 @@ __global__ __launch_bounds__(256) void mask_assemble_kernel(const MaskArgs p) {
   float* const out_img = p.masks + (size_t)b * p.max_dets * p.P;
   uint8_t* const bit_img = p.bitmaps ? p.bitmaps + (size_t)b * p.max_dets * p.P : nullptr;
 
+  // Crop edges and coefficients of detection n are wave-uniform and were written by the previous
+  // kernel: read them through the constant address space so they arrive by scalar loads (SGPRs,
+  // scalar cache) and never wait on this wave's own outstanding vector stores.
+  typedef const __attribute__((address_space(4))) float cfloat;
+  cfloat* const crop_c = (cfloat*)(p.crop + (size_t)b * p.sel_rows);
+  cfloat* const coef_c = (cfloat*)(p.coef + (size_t)b * p.sel_rows * YP_MASK_DIM);
   for (int n = 0; n < N; ++n) {
-    const float4 cb = p.crop[(size_t)b * p.sel_rows + n];           // wave-uniform
-    const float* __restrict__ cf = p.coef + ((size_t)b * p.sel_rows + n) * YP_MASK_DIM;
+    float4 cb;
+    cb.x = crop_c[4 * n + 0]; cb.y = crop_c[4 * n + 1]; cb.z = crop_c[4 * n + 2]; cb.w = crop_c[4 * n + 3];
+    cfloat* const cf = coef_c + n * YP_MASK_DIM;
     bool in[PPL];
     bool any = false;
 #pragma unroll
@@ -132,7 +140,11 @@ hipError_t yp_launch_mask_assemble(const yp_handle* h, int batch, const float* p
   a.max_dets = h->cfg.max_dets; a.sel_rows = h->sel_rows; a.zero_pad = h->cfg.zero_pad_masks;
   a.mask_threshold = h->cfg.mask_threshold;
   const bool al16 = (((uintptr_t)det_masks) & 15u) == 0;
-  if (a.P % 2 == 0 && al16) {
+  const int want = getenv("YP_MASK_PPL") ? atoi(getenv("YP_MASK_PPL")) : 1;
+  if (want == 4 && a.P % 4 == 0 && al16) {
+    const dim3 grid((a.P / 4 + 255) / 256, batch);
+    hipLaunchKernelGGL(mask_assemble_kernel<4>, grid, dim3(256), 0, st, a);
+  } else if (want >= 2 && a.P % 2 == 0 && al16) {
     const dim3 grid((a.P / 2 + 255) / 256, batch);
     hipLaunchKernelGGL(mask_assemble_kernel<2>, grid, dim3(256), 0, st, a);
   } else {

@@ -24,7 +24,8 @@ struct NmsArgs {
   int32_t* cand_count;        // per-class: [B,nseg]
   const int32_t* tile_count;  // [B,ntiles]
   int32_t* stat_surv;         // [B]
-  const float4* dec_box;      // [B,A]
+  const float4* off;          // [B,A] pred_offset (dx,dy,dw,dh)
+  const float4* priors;       // [A]   (ymin,xmin,ymax,xmax) pixels
   u64* pool;                  // [B,nseg,top_k] per-class NMS survivors, final-key format
   int32_t* pool_count;        // [B,nseg]
   float4* crop;               // [B,sel_rows]
@@ -48,12 +49,26 @@ struct SelectShared {
 };
 
 // ---- key sources ---------------------------------------------------------------------------
+// for_each visits every key once, spread over the workgroup's threads.  Loads are issued in
+// batches of YP_SRC_UNROLL independent, unconditional loads (slots past a group's count hold stale
+// keys and are simply skipped) so that one memory round trip serves a whole batch.
+#define YP_SRC_UNROLL 4
 struct ListSrc {   // n contiguous keys (global or LDS)
   const u64* list;
   int n;
   template <int THREADS, class F>
   __device__ __forceinline__ void for_each(F f) const {
-    for (int i = threadIdx.x; i < n; i += THREADS) f(list[i]);
+    for (int i0 = threadIdx.x; i0 < n; i0 += THREADS * YP_SRC_UNROLL) {
+      u64 k[YP_SRC_UNROLL];
+#pragma unroll
+      for (int u = 0; u < YP_SRC_UNROLL; ++u) {
+        const int i = i0 + u * THREADS;
+        k[u] = list[min(i, n - 1)];
+      }
+#pragma unroll
+      for (int u = 0; u < YP_SRC_UNROLL; ++u)
+        if (i0 + u * THREADS < n) f(k[u]);
+    }
   }
 };
 struct SlotSrc {   // nsegs groups of `per` slots; group g holds counts[g] keys at its front
@@ -63,9 +78,19 @@ struct SlotSrc {   // nsegs groups of `per` slots; group g holds counts[g] keys 
   template <int THREADS, class F>
   __device__ __forceinline__ void for_each(F f) const {
     const int total = nsegs * per;
-    for (int s = threadIdx.x; s < total; s += THREADS) {
-      const int g = s / per;
-      if (s - g * per < counts[g]) f(slots[s]);
+    for (int s0 = threadIdx.x; s0 < total; s0 += THREADS * YP_SRC_UNROLL) {
+      u64 k[YP_SRC_UNROLL];
+      int room[YP_SRC_UNROLL];
+#pragma unroll
+      for (int u = 0; u < YP_SRC_UNROLL; ++u) {
+        const int s = min(s0 + u * THREADS, total - 1);
+        const int g = s / per;
+        k[u] = slots[s];
+        room[u] = counts[g] - (s - g * per);
+      }
+#pragma unroll
+      for (int u = 0; u < YP_SRC_UNROLL; ++u)
+        if (s0 + u * THREADS < total && room[u] > 0) f(k[u]);
     }
   }
 };
@@ -140,24 +165,36 @@ __device__ int select_topk_sorted(const Src& src, int n, int want, SelectShared&
   __syncthreads();
   int m;
   if (n <= YP_SORT_MAX) {
-    src.template for_each<THREADS>([&](u64 key) { sh.key[atomicAdd(&sh.fill, 1)] = key; });
+    src.template for_each<THREADS>([&](u64 key) {
+      const int q = atomicAdd(&sh.fill, 1);
+      if (q < YP_SORT_MAX) sh.key[q] = key;
+    });
     m = n;
   } else if (stage != nullptr && n <= YP_STAGE_CAP) {
-    src.template for_each<THREADS>([&](u64 key) { stage[atomicAdd(&sh.fill, 1)] = key; });
+    src.template for_each<THREADS>([&](u64 key) {
+      const int q = atomicAdd(&sh.fill, 1);
+      if (q < YP_STAGE_CAP) stage[q] = key;
+    });
     __syncthreads();
     if (t == 0) sh.fill = 0;
     const ListSrc ls{stage, n};
     u64 prefix, mask;
     radix_select<THREADS>(ls, k, sh, prefix, mask);
     ls.template for_each<THREADS>([&](u64 key) {
-      if ((key & mask) >= prefix) sh.key[atomicAdd(&sh.fill, 1)] = key;
+      if ((key & mask) >= prefix) {
+        const int q = atomicAdd(&sh.fill, 1);
+        if (q < YP_SORT_MAX) sh.key[q] = key;
+      }
     });
     m = k;
   } else {
     u64 prefix, mask;
     radix_select<THREADS>(src, k, sh, prefix, mask);
     src.template for_each<THREADS>([&](u64 key) {
-      if ((key & mask) >= prefix) sh.key[atomicAdd(&sh.fill, 1)] = key;
+      if ((key & mask) >= prefix) {
+        const int q = atomicAdd(&sh.fill, 1);
+        if (q < YP_SORT_MAX) sh.key[q] = key;
+      }
     });
     m = k;
   }
@@ -286,7 +323,11 @@ __global__ __launch_bounds__(THREADS) void cc_nms_kernel(const NmsArgs p) {
   float4 mybox = make_float4(0.f, 0.f, 0.f, 0.f);
   if (t < YP_SORT_MAX) {
     smax[t] = 0;
-    if (t < k) { mybox = p.dec_box[(size_t)b * p.A + yp_seg_key_anchor(sh.key[t])]; sbox[t] = mybox; }   // L187
+    if (t < k) {                                                                        // L187, L79
+      const int a = min(yp_seg_key_anchor(sh.key[t]), p.A - 1);   // (clamp: never index out of bounds)
+      mybox = yp_decode(p.priors[a], p.off[(size_t)b * p.A + a]);
+      sbox[t] = mybox;
+    }
   }
   __syncthreads();
   int pos, total;
@@ -294,7 +335,7 @@ __global__ __launch_bounds__(THREADS) void cc_nms_kernel(const NmsArgs p) {
   const int nk = min(total, p.max_dets);
   if (keep && pos < nk) {
     const u64 key = sh.key[t];
-    const int anchor = yp_seg_key_anchor(key);
+    const int anchor = min(yp_seg_key_anchor(key), p.A - 1);
     s_anchor[pos] = anchor;
     emit_row(p, b, pos, yp_key_score(key), yp_seg_key_class(key), anchor, mybox);   // detection.py:204-207
   }
@@ -315,7 +356,7 @@ __global__ __launch_bounds__(THREADS) void class_nms_kernel(const NmsArgs p) {
   const size_t sidx = (size_t)b * p.nseg + seg;
   const u64* list = p.cand + sidx * p.A;
   // the count and (speculatively) the first 256 keys travel together
-  const int n = p.cand_count[sidx];
+  const int n = min(p.cand_count[sidx], p.A);
   const u64 kspec = list[min(t, p.A - 1)];
   __syncthreads();
   if (t == 0) p.cand_count[sidx] = 0;   // leave the counter ready for the next run
@@ -328,7 +369,10 @@ __global__ __launch_bounds__(THREADS) void class_nms_kernel(const NmsArgs p) {
     // boxes are fetched before the sort; the key's class byte (implied by the segment) carries the
     // slot number so that the sorted order can pick its box up from LDS
     const bool have = t < n;
-    if (have) sbox_u[t] = p.dec_box[(size_t)b * p.A + yp_seg_key_anchor(kspec)];
+    if (have) {
+      const int a = min(yp_seg_key_anchor(kspec), p.A - 1);
+      sbox_u[t] = yp_decode(p.priors[a], p.off[(size_t)b * p.A + a]);                 // detection.py:79
+    }
     if (t < YP_SORT_MAX) sh.key[t] = have ? ((kspec & ~0xFFull) | (u64)t) : 0ull;
     if (t < YP_SORT_MAX) smax[t] = 0;
     __syncthreads();
@@ -355,7 +399,10 @@ __global__ __launch_bounds__(THREADS) void class_nms_kernel(const NmsArgs p) {
     k = select_topk_sorted<THREADS>(ls, n, p.top_k, sh, nullptr);                 // detection.py:217
     if (t < YP_SORT_MAX) {
       smax[t] = 0;
-      if (t < k) sbox[t] = p.dec_box[(size_t)b * p.A + yp_seg_key_anchor(sh.key[t])];   // detection.py:219
+      if (t < k) {                                                                      // detection.py:219
+        const int a = min(yp_seg_key_anchor(sh.key[t]), p.A - 1);   // (clamp: never index out of bounds)
+        sbox[t] = yp_decode(p.priors[a], p.off[(size_t)b * p.A + a]);
+      }
     }
     __syncthreads();
   }
@@ -390,20 +437,22 @@ __global__ __launch_bounds__(THREADS) void final_select_kernel(const NmsArgs p) 
     k = select_topk_sorted<THREADS>(src, n, min(p.max_dets, YP_SORT_MAX), sh, stage);
     if (t < k) {
       const u64 key = sh.key[t];
-      const int anchor = yp_fin_key_anchor(key);
+      const int anchor = min(yp_fin_key_anchor(key), p.A - 1);
       s_anchor[t] = anchor;
-      emit_row(p, b, t, yp_key_score(key), yp_fin_key_class(key), anchor, p.dec_box[(size_t)b * p.A + anchor]);
+      emit_row(p, b, t, yp_key_score(key), yp_fin_key_class(key), anchor,
+               yp_decode(p.priors[anchor], p.off[(size_t)b * p.A + anchor]));
     }
     __syncthreads();
   }
   finish_image<THREADS>(p, b, k, s_anchor, survivors);
 }
 
-static NmsArgs make_args(const yp_handle* h, const float* pred_mask_coef, float* det_boxes, float* det_classes,
+static NmsArgs make_args(const yp_handle* h, const float* pred_offset, const float* priors, const float* pred_mask_coef, float* det_boxes, float* det_classes,
                          float* det_scores, int32_t* num_det, int32_t* kept_idx) {
   NmsArgs a;
   a.cand = h->s.cand; a.cand_count = h->s.cand_count; a.tile_count = h->s.tile_count; a.stat_surv = h->s.stat_surv;
-  a.dec_box = h->s.dec_box; a.pool = h->s.pool; a.pool_count = h->s.pool_count; a.crop = h->s.crop;
+  a.off = reinterpret_cast<const float4*>(pred_offset); a.priors = reinterpret_cast<const float4*>(priors);
+  a.pool = h->s.pool; a.pool_count = h->s.pool_count; a.crop = h->s.crop;
   a.coef_out = h->s.coef; a.coef_in = pred_mask_coef;
   a.det_boxes = det_boxes; a.det_classes = det_classes; a.det_scores = det_scores; a.num_det = num_det;
   a.kept_idx = kept_idx;
@@ -416,10 +465,11 @@ static NmsArgs make_args(const yp_handle* h, const float* pred_mask_coef, float*
   return a;
 }
 
-hipError_t yp_launch_segment_nms(const yp_handle* h, int batch, const float* pred_mask_coef, float* det_boxes,
+hipError_t yp_launch_segment_nms(const yp_handle* h, int batch, const float* pred_offset, const float* priors,
+                                 const float* pred_mask_coef, float* det_boxes,
                                  float* det_classes, float* det_scores, int32_t* num_det, int32_t* kept_idx,
                                  hipStream_t st) {
-  const NmsArgs a = make_args(h, pred_mask_coef, det_boxes, det_classes, det_scores, num_det, kept_idx);
+  const NmsArgs a = make_args(h, pred_offset, priors, pred_mask_coef, det_boxes, det_classes, det_scores, num_det, kept_idx);
   if (h->cfg.nms_mode == YP_NMS_CROSS_CLASS)
     hipLaunchKernelGGL((cc_nms_kernel<1024>), dim3(batch), dim3(1024), 0, st, a);
   else
@@ -427,10 +477,11 @@ hipError_t yp_launch_segment_nms(const yp_handle* h, int batch, const float* pre
   return hipGetLastError();
 }
 
-hipError_t yp_launch_final_select(const yp_handle* h, int batch, const float* pred_mask_coef, float* det_boxes,
+hipError_t yp_launch_final_select(const yp_handle* h, int batch, const float* pred_offset, const float* priors,
+                                  const float* pred_mask_coef, float* det_boxes,
                                   float* det_classes, float* det_scores, int32_t* num_det, int32_t* kept_idx,
                                   hipStream_t st) {
-  const NmsArgs a = make_args(h, pred_mask_coef, det_boxes, det_classes, det_scores, num_det, kept_idx);
+  const NmsArgs a = make_args(h, pred_offset, priors, pred_mask_coef, det_boxes, det_classes, det_scores, num_det, kept_idx);
   hipLaunchKernelGGL((final_select_kernel<1024>), dim3(batch), dim3(1024), 0, st, a);
   return hipGetLastError();
 }

@@ -14,15 +14,13 @@
 
 struct ScoreFilterArgs {
   const float* cls;      // [B,A,C]
-  const float* off;      // [B,A,4]
-  const float* priors;   // [A,4]
   u64* cand;             // cross-class: [B, ntiles*TA] tile-major slots; per-class: [B,nseg,A] lists
   int32_t* cand_count;   // per-class: [B,nseg] list lengths (atomic append)
   int32_t* tile_count;   // [B,ntiles] survivors of every tile (plain store; doubles as the slot count)
-  float4* dec_box;       // [B,A]
   int A, C, stride, nseg, ntiles;
   float conf, conf_lo;
   float pre_thresh;      // ln(1/conf - 1) + 1e-3: x_bg - x_fgmax must be below it to have p_fgmax > conf
+  int ablate;            // TEMP debug
 };
 
 // ---- cross-lane helpers: DPP moves inside a row of 16 lanes (one VALU op, no LDS round trip) ----
@@ -74,7 +72,8 @@ typedef const __attribute__((address_space(1))) void glb_void;
 //   phase 2  the remaining anchors, four at a time, 16 lanes per anchor: lane j owns classes
 //            j, j+16, ... - exactly the 16 strided partial sums of the YP-MATH softmax - so the
 //            denominator is a per-lane sequential sum plus one DPP tree (8,4,2,1)
-//   phase 3  survivors: keys appended to the image's candidate list(s), boxes decoded
+//   phase 3  survivors' keys go to the image's candidate slots / per-class lists (stores only; the
+//            boxes are decoded later, for the few candidates that reach the NMS)
 template <int MODE, int CPL, int TA>
 __global__ __launch_bounds__(YP_WAVE) void score_filter_kernel(const ScoreFilterArgs p) {
   constexpr int LPA = YP_WAVE / TA;   // lanes per anchor in phase 1
@@ -88,12 +87,11 @@ __global__ __launch_bounds__(YP_WAVE) void score_filter_kernel(const ScoreFilter
   const float* __restrict__ src = p.cls + ((size_t)b * p.A + a0) * C;
   // small per-wave lists behind the tile
   int* s_list = reinterpret_cast<int*>(tile + TA * p.stride);   // tile-local anchors that passed phase 1
-  int* s_anch = s_list + TA;                                      // tile-local index of survivors
-  u64* s_key = reinterpret_cast<u64*>(s_anch + TA);               // keys waiting to be written out
+  u64* s_key = reinterpret_cast<u64*>(s_list + YP_WAVE);          // keys waiting to be written out
   constexpr int KCAP = 128;                                       // capacity of s_key
 
   // ---- phase 0: global -> LDS ------------------------------------------------------------------
-  if (p.stride == C && (((uintptr_t)src) & 15u) == 0) {
+  if (p.ablate & 4) {} else if (p.stride == C && (((uintptr_t)src) & 15u) == 0) {
     const int nvec = nelem >> 2;
     const float4* __restrict__ src4 = reinterpret_cast<const float4*>(src);
     for (int v0 = 0; v0 < nvec; v0 += YP_WAVE) {
@@ -131,7 +129,7 @@ __global__ __launch_bounds__(YP_WAVE) void score_filter_kernel(const ScoreFilter
   }
   const u64 lt_mask = (1ull << lane) - 1ull;
   const u64 pm = __ballot(pre);
-  const int npass = __popcll(pm);
+  const int npass = (p.ablate & 2) ? 0 : ((p.ablate & 8) ? min(4, __popcll(pm)) : __popcll(pm));
   if (pre) s_list[__popcll(pm & lt_mask)] = al1;
   __syncthreads();
 
@@ -152,7 +150,7 @@ __global__ __launch_bounds__(YP_WAVE) void score_filter_kernel(const ScoreFilter
       const int c = j + 16 * i;
       const bool ok = c < C;
       const float x = r[ok ? c : 0];
-      e[i] = ok ? yp_exp(x - ma) : 0.0f;
+      e[i] = ok ? yp_exp_le0(x - ma) : 0.0f;              // x <= row max
       s = s + e[i];                                        // s_j = e_j + e_{j+16} + ...
       if (i > 0) em = fmaxf(em, e[i]);
       else if (j > 0) em = e[0];                           // class 0 is background (detection.py:59)
@@ -180,10 +178,7 @@ __global__ __launch_bounds__(YP_WAVE) void score_filter_kernel(const ScoreFilter
         }
       }
       arg = grp16_min(arg);
-      if (lead) {
-        s_anch[pos] = al;
-        s_key[pos] = yp_seg_key(pmax, a0 + al, arg);
-      }
+      if (lead) s_key[pos] = yp_seg_key(pmax, a0 + al, arg);
     } else {
       // per-class candidates: every (anchor, class) with p > conf                   (detection.py:233)
       // They are parked in LDS and appended to the per-class lists 64 at a time, so that the
@@ -215,12 +210,11 @@ __global__ __launch_bounds__(YP_WAVE) void score_filter_kernel(const ScoreFilter
           }
         }
       }
-      if (lead) s_anch[pos] = al;
     }
     nk += __popcll(bl);
   }
-  if (lane == 0) p.tile_count[(size_t)b * p.ntiles + blockIdx.x] = nk;
-  if (nk == 0) return;
+  if (lane == 0) p.tile_count[(size_t)b * p.ntiles + blockIdx.x] = (p.ablate & 1) ? 0 : nk;
+  if (nk == 0 || (p.ablate & 1)) return;
   __syncthreads();
 
   // ---- phase 3: survivors ---------------------------------------------------------------------
@@ -233,25 +227,6 @@ __global__ __launch_bounds__(YP_WAVE) void score_filter_kernel(const ScoreFilter
       const int qpos = atomicAdd(&p.cand_count[seg], 1);
       p.cand[seg * p.A + qpos] = key;
     }
-  }
-  if (lane < nk) {   // utils._decode, utils/utils.py:193-213
-    const int a = a0 + s_anch[lane];
-    const float4 pr = reinterpret_cast<const float4*>(p.priors)[a];                       // y0,x0,y1,x1
-    const float4 of = reinterpret_cast<const float4*>(p.off)[(size_t)b * p.A + a];        // dx,dy,dw,dh
-    const float ph = pr.z - pr.x;
-    const float pw = pr.w - pr.y;
-    const float cx = pr.y + (pw / 2.0f);
-    const float cy = pr.x + (ph / 2.0f);
-    const float bx = cx + (of.x * pw) * 0.1f;
-    const float by = cy + (of.y * ph) * 0.1f;
-    const float bw = pw * yp_exp(of.z * 0.2f);
-    const float bh = ph * yp_exp(of.w * 0.2f);
-    float4 box;
-    box.y = bx - bw / 2.0f;   // xmin
-    box.x = by - bh / 2.0f;   // ymin
-    box.w = bw / 2.0f + bx;   // xmax
-    box.z = bh / 2.0f + by;   // ymax
-    p.dec_box[(size_t)b * p.A + a] = box;
   }
 }
 
@@ -266,18 +241,18 @@ static void launch_mode(int cpl, int A, int batch, size_t lds, hipStream_t st, c
 #undef YP_SF_CASE
 }
 
-hipError_t yp_launch_score_filter(const yp_handle* h, int batch, const float* pred_cls, const float* pred_offset,
-                                  const float* priors, hipStream_t st) {
+hipError_t yp_launch_score_filter(const yp_handle* h, int batch, const float* pred_cls, hipStream_t st) {
   ScoreFilterArgs a;
-  a.cls = pred_cls; a.off = pred_offset; a.priors = priors;
-  a.cand = h->s.cand; a.cand_count = h->s.cand_count; a.tile_count = h->s.tile_count; a.dec_box = h->s.dec_box;
+  a.cls = pred_cls;
+  a.cand = h->s.cand; a.cand_count = h->s.cand_count; a.tile_count = h->s.tile_count;
   a.A = h->cfg.num_anchors; a.C = h->cfg.num_classes; a.stride = h->lds_stride; a.nseg = h->nseg;
   a.conf = h->cfg.conf_thresh;
   a.conf_lo = h->cfg.conf_thresh * (1.0f - 0x1p-20f);
   a.pre_thresh = h->pre_thresh;
+  a.ablate = getenv("YP_ABLATE") ? atoi(getenv("YP_ABLATE")) : 0;
   const int TA = h->tile_anchors;
   a.ntiles = h->ntiles;
-  const size_t lds = (size_t)TA * a.stride * sizeof(float) + TA * 2 * sizeof(int) + 128 * sizeof(u64);
+  const size_t lds = (size_t)TA * a.stride * sizeof(float) + YP_WAVE * sizeof(int) + 128 * sizeof(u64);
   int cpl = (a.C + 15) / 16;                       // classes per lane in phase 2
   if (cpl == 7) cpl = 8; else if (cpl > 8 && cpl <= 12) cpl = 12; else if (cpl > 12) cpl = 16;
   const bool cc = h->cfg.nms_mode == YP_NMS_CROSS_CLASS;

@@ -1,0 +1,86 @@
+"""Image sharding of a batch over GPUs.
+
+Images are independent in Detect (the reference loops over them, detection.py:71) and `priors` is
+the only shared, read-only input, so a batch splits into contiguous chunks with NO data-path
+collective: each GPU runs the whole hot path on its chunk and the results are concatenated in
+image order.  Two forms:
+
+* `ShardedDetect`  one process, one `Detect` per visible GPU, chunks launched back to back on
+  each device's stream, host-side concatenation;
+* `shard_bounds` / `gather_results`  one process per GPU (torch.distributed): every rank takes
+  its chunk, rank `dst` receives the concatenated result (gather_object; RCCL is not needed for
+  correctness, any backend works - the CPU tests use gloo).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+RESULT_KEYS = ("detection_boxes", "detection_classes", "detection_scores", "detection_masks",
+               "num_detections", "detection_anchor_indices")
+
+
+def shard_bounds(batch: int, world: int, rank: int):
+    """Contiguous chunk [lo, hi) of `batch` images for `rank` of `world`; sizes differ by at most 1."""
+    if world < 1 or not (0 <= rank < world):
+        raise ValueError("bad world/rank")
+    base, extra = divmod(batch, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def slice_net_outs(net_outs: dict, lo: int, hi: int) -> dict:
+    """The chunk of every per-image tensor; `priors` is replicated."""
+    return {k: (v if k == "priors" else v[lo:hi]) for k, v in net_outs.items()}
+
+
+def concat_results(parts):
+    """Concatenate per-chunk result dicts (numpy or torch-on-host) in image order; empty chunks are skipped."""
+    parts = [p for p in parts if p is not None and len(p["num_detections"]) > 0]
+    if not parts:
+        raise ValueError("no results")
+    out = {}
+    for k in parts[0]:
+        vals = [p[k] for p in parts]
+        if vals[0] is None:
+            out[k] = None
+        elif hasattr(vals[0], "numpy") and not isinstance(vals[0], np.ndarray):
+            import torch
+            out[k] = torch.cat(vals, dim=0)
+        else:
+            out[k] = np.concatenate(vals, axis=0)
+    return out
+
+
+def gather_results(local: dict | None, dst: int = 0):
+    """torch.distributed: rank `dst` gets the concatenation of every rank's result dict (host tensors)."""
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(), dist.get_rank()
+    bucket = [None] * world if rank == dst else None
+    dist.gather_object(local, bucket, dst=dst)
+    return concat_results(bucket) if rank == dst else None
+
+
+class ShardedDetect:
+    """`Detect` over several GPUs of one node from a single process."""
+
+    def __init__(self, *detect_args, devices=None, **detect_kwargs):
+        import torch
+        from .detect import Detect
+        if not torch.cuda.is_available():
+            raise RuntimeError("ShardedDetect needs HIP devices; there is no CPU fallback")
+        self.devices = list(devices) if devices is not None else list(range(torch.cuda.device_count()))
+        self.detects = [Detect(*detect_args, device=f"cuda:{d}", **detect_kwargs) for d in self.devices]
+
+    def __call__(self, net_outs, img_shape, trad_nms=False, use_cropped_mask=True):
+        import torch
+        B = int(net_outs["pred_cls"].shape[0])
+        G = len(self.devices)
+        parts = []
+        for r, det in enumerate(self.detects):            # launches are asynchronous: devices overlap
+            lo, hi = shard_bounds(B, G, r)
+            if hi > lo:
+                parts.append(det(slice_net_outs(net_outs, lo, hi), img_shape, trad_nms, use_cropped_mask))
+        host = []
+        for p in parts:                                   # gather on the host, in image order
+            host.append({k: v.cpu() for k, v in p.items()})
+        return concat_results(host)
