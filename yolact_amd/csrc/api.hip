@@ -70,7 +70,7 @@ extern "C" int yp_create(const yp_config* cfg, yp_handle** out) {
     const int v = atoi(ev);
     if (v == 16 || v == 32 || v == 64) h->tile_anchors = v;
   }
-  if ((size_t)YP_WAVE * h->lds_stride * sizeof(float) > 64 * 1024) { delete h; return fail(YP_EINVAL, "num_classes too large for the LDS tile"); }
+  while (h->tile_anchors > 16 && (size_t)h->tile_anchors * h->lds_stride * sizeof(float) > 60 * 1024) h->tile_anchors /= 2;
 
   h->ntiles = (c.num_anchors + h->tile_anchors - 1) / h->tile_anchors;
   const size_t B = (size_t)c.max_batch, A = (size_t)c.num_anchors, nseg = (size_t)h->nseg;
