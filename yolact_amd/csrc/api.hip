@@ -65,12 +65,23 @@ extern "C" int yp_create(const yp_config* cfg, yp_handle** out) {
     const double cf = (double)c.conf_thresh;
     h->pre_thresh = cf > 0.0 ? (float)(log(1.0 / cf - 1.0) + 1e-3) : INFINITY;
   }
+  {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c.device_id) != hipSuccess || cus < 1) cus = 256;
+    h->num_cus = cus;
+  }
   h->tile_anchors = 32;
   if (const char* ev = getenv("YP_TILE_ANCHORS")) {   // tuning knob for benchmarks
     const int v = atoi(ev);
     if (v == 16 || v == 32 || v == 64) h->tile_anchors = v;
   }
-  while (h->tile_anchors > 16 && (size_t)h->tile_anchors * h->lds_stride * sizeof(float) > 60 * 1024) h->tile_anchors /= 2;
+  for (;;) {   // two LDS tile buffers per wave must fit the 64 KiB a workgroup may take without opt-in
+    const int tile_bytes = h->tile_anchors * h->lds_stride * (int)sizeof(float);
+    h->sf_ndma = (h->tile_anchors * c.num_classes * (int)sizeof(float) + 1023) / 1024;
+    h->sf_bufb = h->sf_ndma * 1024 > tile_bytes ? h->sf_ndma * 1024 : (tile_bytes + 15) / 16 * 16;
+    if (2 * h->sf_bufb + 2048 <= 64 * 1024 || h->tile_anchors == 16) break;
+    h->tile_anchors /= 2;
+  }
 
   h->ntiles = (c.num_anchors + h->tile_anchors - 1) / h->tile_anchors;
   const size_t B = (size_t)c.max_batch, A = (size_t)c.num_anchors, nseg = (size_t)h->nseg;
@@ -105,6 +116,9 @@ extern "C" int yp_create(const yp_config* cfg, yp_handle** out) {
     return fail(YP_EHIP, "hipMemset of the counters failed");
   }
   (void)hipDeviceSynchronize();   // the counters are zero before any stream can run score_filter
+#ifdef YP_SF_STAMPS
+  (void)hipMalloc(&h->dbg, 64 * 65536); (void)hipMemset(h->dbg, 0, 64 * 65536);
+#endif
   *out = h;
   g_err[0] = 0;
   return YP_OK;
@@ -114,6 +128,18 @@ extern "C" int yp_destroy(yp_handle* h) {
   if (!h) return YP_OK;
   (void)hipSetDevice(h->cfg.device_id);
   (void)hipDeviceSynchronize();
+#ifdef YP_SF_STAMPS
+  {
+    unsigned long long* all = (unsigned long long*)malloc(64 * 65536);
+    (void)hipMemcpy(all, h->dbg, 64 * 65536, hipMemcpyDeviceToHost);
+    unsigned long long d[8] = {0};
+    for (int w = 0; w < 65536; ++w) for (int i = 0; i < 7; ++i) d[i] += all[w * 8 + i];
+    free(all);
+    const double n = d[5] ? (double)d[5] : 1.0;
+    fprintf(stderr, "[yp stamps] tiles=%llu phase0(wait+issue)=%.0f of which wait=%.0f phase1=%.0f phase2=%.0f phase3=%.0f cycles/tile npass=%.2f\n", d[5], d[0]/n, d[1]/n, d[2]/n, d[3]/n, d[4]/n, d[6]/n);
+    (void)hipFree(h->dbg);
+  }
+#endif
   if (h->profile) for (int i = 0; i <= YP_NUM_KERNELS; ++i) (void)hipEventDestroy(h->ev[i]);
   (void)hipFree(h->scratch_base);
   delete h;

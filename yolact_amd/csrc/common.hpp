@@ -129,6 +129,11 @@ struct yp_handle {
   float pre_thresh;     // score_filter's early-reject bound on x_bg - x_fgmax
   int tile_anchors;     // TA: anchors per score_filter wave (16, 32 or 64)
   int ntiles;           // ceil(A / TA)
+  int num_cus;          // compute units of the device (256 on MI355X)
+  int sf_ndma, sf_bufb; // score_filter: LDS-DMA instructions per tile, bytes per LDS tile buffer
+#ifdef YP_SF_STAMPS
+  void* dbg;            // diagnostic build only
+#endif
   void* scratch_base;
   int64_t scratch_bytes;
   yp_scratch s;

@@ -17,10 +17,16 @@ struct ScoreFilterArgs {
   u64* cand;             // cross-class: [B, ntiles*TA] tile-major slots; per-class: [B,nseg,A] lists
   int32_t* cand_count;   // per-class: [B,nseg] list lengths (atomic append)
   int32_t* tile_count;   // [B,ntiles] survivors of every tile (plain store; doubles as the slot count)
-  int A, C, stride, nseg, ntiles;
+  int A, C, stride, nseg, ntiles, batch;
+  int bufb;              // bytes of one LDS tile buffer (>= ndma KiB and >= TA*stride*4)
+  int ndma;              // LDS-DMA wave-instructions per tile: ceil(TA*C*4 / 1024)
+  int fast;              // 1: stride == C and every tile starts 16-byte aligned -> LDS-DMA path
+#ifdef YP_SF_STAMPS
+  unsigned long long* dbg;   // diagnostic build only: per-wave phase cycle sums
+  int ablate;
+#endif
   float conf, conf_lo;
   float pre_thresh;      // ln(1/conf - 1) + 1e-3: x_bg - x_fgmax must be below it to have p_fgmax > conf
-  int ablate;            // TEMP debug
 };
 
 // ---- cross-lane helpers: DPP moves inside a row of 16 lanes (one VALU op, no LDS round trip) ----
@@ -45,11 +51,29 @@ __device__ __forceinline__ float grp16_sum(float v) {
   v = v + dpp_f<YP_DPP_ROR(1)>(v);
   return v;
 }
-__device__ __forceinline__ float grp16_max(float v) {
-  v = fmaxf(v, dpp_f<YP_DPP_ROR(8)>(v));
-  v = fmaxf(v, dpp_f<YP_DPP_ROR(4)>(v));
-  v = fmaxf(v, dpp_f<YP_DPP_ROR(2)>(v));
-  v = fmaxf(v, dpp_f<YP_DPP_ROR(1)>(v));
+// max of three floats in one instruction (no NaN canonicalisation passes; logits are finite)
+__device__ __forceinline__ float max3f(float a, float b, float c) {
+  float d;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+// max over a row of 16 lanes of NON-NEGATIVE floats: their bit patterns order like integers
+__device__ __forceinline__ float grp16_max_nonneg(float f) {
+  int v = __builtin_bit_cast(int, f);
+  v = max(v, dpp_i<YP_DPP_ROR(8)>(v));
+  v = max(v, dpp_i<YP_DPP_ROR(4)>(v));
+  v = max(v, dpp_i<YP_DPP_ROR(2)>(v));
+  v = max(v, dpp_i<YP_DPP_ROR(1)>(v));
+  return __builtin_bit_cast(float, v);
+}
+__device__ __forceinline__ float max_nonneg(float a, float b) {
+  return __builtin_bit_cast(float, max(__builtin_bit_cast(int, a), __builtin_bit_cast(int, b)));
+}
+__device__ __forceinline__ int grp16_sum_i(int v) {
+  v = v + dpp_i<YP_DPP_ROR(8)>(v);
+  v = v + dpp_i<YP_DPP_ROR(4)>(v);
+  v = v + dpp_i<YP_DPP_ROR(2)>(v);
+  v = v + dpp_i<YP_DPP_ROR(1)>(v);
   return v;
 }
 __device__ __forceinline__ int grp16_min(int v) {
@@ -63,9 +87,27 @@ __device__ __forceinline__ int grp16_min(int v) {
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void glb_void;
 
-// One wave = one tile of TA consecutive anchors (TA = 16, 32 or 64).
+// s_waitcnt vmcnt(n) with a run-time (wave-uniform) n: "wait until at most n vector-memory
+// operations of this wave are outstanding".  Counts above 6 fall back to a full drain.
+__device__ __forceinline__ void wait_vmcnt_le(int n) {
+  switch (n) {
+    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+  }
+}
+
+// One PERSISTENT wave walks tiles of TA consecutive anchors (TA = 16, 32 or 64): tile blockIdx.x,
+// blockIdx.x + gridDim.x, ...  Two LDS buffers: while tile i is being processed, the LDS-DMA of
+// tile i+1 is in flight, so every resident wave always has HBM reads outstanding.
 //   phase 0  the tile's TA*C logits, contiguous in HBM, go straight into LDS with LDS-DMA
-//            (global_load_lds_dwordx4: 1 KiB per wave-instruction, no VGPR staging, all in flight)
+//            (global_load_lds_dwordx4: 1 KiB per wave-instruction, no VGPR staging); always exactly
+//            `ndma` full-wave instructions per tile (addresses past the tile are clamped, the
+//            excess lands in the buffer's padding)
 //   phase 1  64/TA lanes per anchor: x_bg, max foreground logit, row max; exact-safe early reject:
 //            p_fgmax <= 1/(1+exp(x_bg-x_fgmax)), so an anchor with x_bg-x_fgmax >= ln(1/conf-1)+1e-3
 //            cannot pass `class_p_max > conf` (detection.py:73) and needs no exponentials at all
@@ -73,166 +115,327 @@ typedef const __attribute__((address_space(1))) void glb_void;
 //            j, j+16, ... - exactly the 16 strided partial sums of the YP-MATH softmax - so the
 //            denominator is a per-lane sequential sum plus one DPP tree (8,4,2,1)
 //   phase 3  survivors' keys go to the image's candidate slots / per-class lists (stores only; the
-//            boxes are decoded later, for the few candidates that reach the NMS)
+//            boxes are decoded later, for the few candidates that reach the NMS).  The stores are
+//            not waited for: the wait for tile i+1's DMA is a COUNTED vmcnt that leaves exactly the
+//            store instructions issued after that DMA in flight.
 template <int MODE, int CPL, int TA>
 __global__ __launch_bounds__(YP_WAVE) void score_filter_kernel(const ScoreFilterArgs p) {
   constexpr int LPA = YP_WAVE / TA;   // lanes per anchor in phase 1
-  extern __shared__ __align__(16) float tile[];
+  constexpr int KCAP = 128;           // capacity of the key list
+  extern __shared__ __align__(16) char lds_raw[];
   const int lane = threadIdx.x;
-  const int b = blockIdx.y;
-  const int a0 = blockIdx.x * TA;
-  const int na = min(TA, p.A - a0);
   const int C = p.C;
-  const int nelem = na * C;
-  const float* __restrict__ src = p.cls + ((size_t)b * p.A + a0) * C;
-  // small per-wave lists behind the tile
-  int* s_list = reinterpret_cast<int*>(tile + TA * p.stride);   // tile-local anchors that passed phase 1
+  int2* s_list = reinterpret_cast<int2*>(lds_raw + 2 * p.bufb);  // (tile-local anchor, row max) of anchors past phase 1
   u64* s_key = reinterpret_cast<u64*>(s_list + YP_WAVE);          // keys waiting to be written out
-  constexpr int KCAP = 128;                                       // capacity of s_key
-
-  // ---- phase 0: global -> LDS ------------------------------------------------------------------
-  if (p.ablate & 4) {} else if (p.stride == C && (((uintptr_t)src) & 15u) == 0) {
-    const int nvec = nelem >> 2;
-    const float4* __restrict__ src4 = reinterpret_cast<const float4*>(src);
-    for (int v0 = 0; v0 < nvec; v0 += YP_WAVE) {
-      if (v0 + lane < nvec)
-        __builtin_amdgcn_global_load_lds((glb_void*)(src4 + v0 + lane), (lds_void*)(tile + 4 * v0), 16, 0, 0);
-    }
-    for (int e = (nvec << 2) + lane; e < nelem; e += YP_WAVE) tile[e] = src[e];
-  } else {
-    for (int e = lane; e < nelem; e += YP_WAVE) {
-      const int a = e / C;
-      tile[a * p.stride + (e - a * C)] = src[e];
-    }
-  }
-  __syncthreads();   // (single wave) waits vmcnt(0): every DMA piece has landed
-
-  // ---- phase 1: LPA lanes per anchor ----------------------------------------------------------
-  const int al1 = lane / LPA, q = lane % LPA;
-  float m;
-  bool pre;
-  {
-    const float* row = tile + min(al1, na - 1) * p.stride;
-    const float x0 = row[0];
-    float xf = -INFINITY;
-    for (int c0 = 1 + q; c0 < C; c0 += 16 * LPA) {
-      float v[16];
+  const int grp = lane >> 4, j = lane & 15;
+  int cidx[CPL];     // this lane's classes j, j+16, ... (clamped) and whether they exist
+  float okf[CPL];
 #pragma unroll
-      for (int j = 0; j < 16; ++j) v[j] = row[min(c0 + LPA * j, C - 1)];
-#pragma unroll
-      for (int j = 0; j < 16; ++j) xf = fmaxf(xf, v[j]);
-    }
-    if (LPA >= 2) xf = fmaxf(xf, dpp_f<YP_DPP_XOR1>(xf));
-    if (LPA >= 4) xf = fmaxf(xf, dpp_f<YP_DPP_XOR2>(xf));
-    m = fmaxf(x0, xf);
-    pre = (al1 < na) && (q == 0) && ((x0 - xf) < p.pre_thresh);
+  for (int i = 0; i < CPL; ++i) {
+    cidx[i] = min(j + 16 * i, C - 1);
+    okf[i] = (j + 16 * i) < C ? 1.0f : 0.0f;
   }
   const u64 lt_mask = (1ull << lane) - 1ull;
-  const u64 pm = __ballot(pre);
-  const int npass = (p.ablate & 2) ? 0 : ((p.ablate & 8) ? min(4, __popcll(pm)) : __popcll(pm));
-  if (pre) s_list[__popcll(pm & lt_mask)] = al1;
-  __syncthreads();
+  const int total_tiles = p.batch * p.ntiles;
+  const uint32_t lds_base = (uint32_t)(uintptr_t)(lds_void*)lds_raw;
+  const uint32_t lane16 = (uint32_t)lane * 16u;
+  const long long img_bytes = (long long)p.A * C * 4;
+  const long long tile_bytes = (long long)TA * C * 4;
+  const long long all_bytes = (long long)p.batch * img_bytes;
 
-  // ---- phase 2: 16 lanes per anchor -----------------------------------------------------------
-  const int grp = lane >> 4, j = lane & 15;
-  int nk = 0;      // survivors so far (wave-uniform)
-  int ncand = 0;   // per-class candidates parked in s_key (wave-uniform)
-  for (int t0 = 0; t0 < npass; t0 += 4) {
-    const int slot = t0 + grp;
-    const bool act = slot < npass;
-    const int al = act ? s_list[slot] : 0;
-    const float ma = __shfl(m, al * LPA);
-    const float* r = tile + al * p.stride;
-    float e[CPL];
-    float s = 0.0f, em = 0.0f;
-#pragma unroll
-    for (int i = 0; i < CPL; ++i) {
-      const int c = j + 16 * i;
-      const bool ok = c < C;
-      const float x = r[ok ? c : 0];
-      e[i] = ok ? yp_exp_le0(x - ma) : 0.0f;              // x <= row max
-      s = s + e[i];                                        // s_j = e_j + e_{j+16} + ...
-      if (i > 0) em = fmaxf(em, e[i]);
-      else if (j > 0) em = e[0];                           // class 0 is background (detection.py:59)
+  // LDS-DMA of one whole tile: exactly p.ndma wave-instructions, every lane active (bytes past the
+  // tile's end land in the buffer's padding).  Inline asm, so that the compiler's own s_waitcnt
+  // bookkeeping does not drain the prefetch of the NEXT tile before every LDS read of the current
+  // one (it cannot tell the two buffers apart); the DMA is waited for by hand with the counted wait
+  // at the top of the tile loop.  Scalar base + lane*16 + immediate; the immediate offset applies
+  // to the LDS address as well, so four 1 KiB pieces share one M0.
+  auto issue_dma = [&](int bb, int tt, uint32_t buf_off) {
+    const long long off = bb * img_bytes + tt * tile_bytes;
+    const char* gbase = reinterpret_cast<const char*>(p.cls) + off;
+    uint32_t dst = lds_base + buf_off;
+    int left = p.ndma;
+    if (off + (long long)left * 1024 > all_bytes) {
+      // only the last tile of the buffer: never read past the caller's allocation (clamped lanes)
+      const char* const last = reinterpret_cast<const char*>(p.cls) + all_bytes - 16;
+      for (; left > 0; --left, gbase += 1024, dst += 1024) {
+        const char* g = gbase + lane16;
+        g = g < last ? g : last;
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(dst) : "memory");
+      }
+      return;
     }
-    const float S = grp16_sum(s);
-    em = grp16_max(em);
-    // IEEE division is monotone, so max_c fl(e_c/S) = fl(max_c e_c / S)                (detection.py:62)
-    const float pmax = em / S;
-    const bool surv = act && (pmax > p.conf);                                        // detection.py:73
-    const bool lead = surv && j == 0;
-    const u64 bl = __ballot(lead);
-    const int pos = nk + __popcll(bl & lt_mask);
-    if (MODE == YP_NMS_CROSS_CLASS) {
-      // tf.argmax over the probabilities (detection.py:184): the FIRST class whose rounded
-      // probability equals the maximum.  Only an e_c within 2^-21 of the largest can round to it.
-      int arg = 0x7fffffff;
-      if (surv) {
+    for (; left >= 4; left -= 4, gbase += 4096, dst += 4096)
+      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                   "global_load_lds_dwordx4 %0, %1\n\t"
+                   "global_load_lds_dwordx4 %0, %1 offset:1024\n\t"
+                   "global_load_lds_dwordx4 %0, %1 offset:2048\n\t"
+                   "global_load_lds_dwordx4 %0, %1 offset:3072" ::"v"(lane16), "s"(gbase), "s"(dst) : "memory");
+    if (left == 3)
+      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                   "global_load_lds_dwordx4 %0, %1\n\t"
+                   "global_load_lds_dwordx4 %0, %1 offset:1024\n\t"
+                   "global_load_lds_dwordx4 %0, %1 offset:2048" ::"v"(lane16), "s"(gbase), "s"(dst) : "memory");
+    else if (left == 2)
+      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                   "global_load_lds_dwordx4 %0, %1\n\t"
+                   "global_load_lds_dwordx4 %0, %1 offset:1024" ::"v"(lane16), "s"(gbase), "s"(dst) : "memory");
+    else if (left == 1)
+      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                   "global_load_lds_dwordx4 %0, %1" ::"v"(lane16), "s"(gbase), "s"(dst) : "memory");
+  };
+
+  int flat = blockIdx.x;
+  if (flat >= total_tiles) return;
+  const int G = gridDim.x;
+  int b = flat / p.ntiles, tix = flat - b * p.ntiles;       // current tile
+  int nb = b, ntix = tix;                                    // next tile of this wave
+  auto advance = [&](int& bb, int& tt) {
+    tt += G;
+    while (tt >= p.ntiles) { tt -= p.ntiles; ++bb; }
+  };
+  if (p.fast) issue_dma(b, tix, 0u);
+  advance(nb, ntix);
+  int nst = 0;    // store instructions issued since the last DMA issue (wave-uniform)
+#ifdef YP_SF_STAMPS
+  long long dd[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define STAMP(v) const long long v = clock64()
+#else
+#define STAMP(v)
+#endif
+  int par = 0;
+  for (; flat < total_tiles; flat += G, par ^= 1, b = nb, tix = ntix, advance(nb, ntix)) {
+    const int a0 = tix * TA;
+    const int na = min(TA, p.A - a0);
+    float* tile = reinterpret_cast<float*>(lds_raw + (par ? p.bufb : 0));
+
+    // ---- phase 0 ------------------------------------------------------------------------------
+    STAMP(T0);
+    if (p.fast) {
+      wait_vmcnt_le(nst);                      // this tile's DMA has landed; younger stores stay in flight
+#ifdef YP_SF_STAMPS
+      dd[1] += clock64() - T0;
+#endif
+      if (flat + G < total_tiles) issue_dma(nb, ntix, par ? 0u : (uint32_t)p.bufb);
+      nst = 0;
+    } else {
+      const int nelem = na * C;
+      const float* __restrict__ src = p.cls + ((size_t)b * p.A + a0) * C;
+      for (int e = lane; e < nelem; e += YP_WAVE) {
+        const int a = e / C;
+        tile[a * p.stride + (e - a * C)] = src[e];
+      }
+      __syncthreads();
+    }
+
+    STAMP(T2);
+    // ---- phase 1: LPA lanes per anchor --------------------------------------------------------
+    const int al1 = lane / LPA, q = lane % LPA;
+    float m;
+    bool pre;
+    {
+      const float* row = tile + min(al1, na - 1) * p.stride;
+      const float x0 = row[0];
+      float xf = -INFINITY;
+      int c0 = 1 + q;
+      for (; c0 + LPA * 15 < C; c0 += 16 * LPA) {     // full chunks: base + immediate offsets
+        float v[16];
+#pragma unroll
+        for (int jj = 0; jj < 16; ++jj) v[jj] = row[c0 + LPA * jj];
+        const float t0 = max3f(v[0], v[1], v[2]), t1 = max3f(v[3], v[4], v[5]), t2 = max3f(v[6], v[7], v[8]);
+        const float t3 = max3f(v[9], v[10], v[11]), t4 = max3f(v[12], v[13], v[14]);
+        xf = max3f(max3f(t0, t1, t2), max3f(t3, t4, v[15]), xf);
+      }
+      if (c0 < C) {                                   // ragged tail, clamped
+        float v[16];
+#pragma unroll
+        for (int jj = 0; jj < 16; ++jj) v[jj] = row[min(c0 + LPA * jj, C - 1)];
+        const float t0 = max3f(v[0], v[1], v[2]), t1 = max3f(v[3], v[4], v[5]), t2 = max3f(v[6], v[7], v[8]);
+        const float t3 = max3f(v[9], v[10], v[11]), t4 = max3f(v[12], v[13], v[14]);
+        xf = max3f(max3f(t0, t1, t2), max3f(t3, t4, v[15]), xf);
+      }
+      if (LPA >= 2) xf = fmaxf(xf, dpp_f<YP_DPP_XOR1>(xf));
+      if (LPA >= 4) xf = fmaxf(xf, dpp_f<YP_DPP_XOR2>(xf));
+      m = fmaxf(x0, xf);
+      pre = (al1 < na) && (q == 0) && ((x0 - xf) < p.pre_thresh);
+    }
+    const u64 pm = __ballot(pre);
+#ifdef YP_SF_STAMPS
+    const int npass = p.ablate == 2 ? 0 : __popcll(pm);
+#else
+    const int npass = __popcll(pm);
+#endif
+    if (pre) s_list[__popcll(pm & lt_mask)] = make_int2(al1, __float_as_int(m));   // (tile-local anchor, row max)
+    __builtin_amdgcn_wave_barrier();   // single wave: LDS operations execute in order
+
+    STAMP(T3);
+    // ---- phase 2: 16 lanes per anchor ---------------------------------------------------------
+    // Straight-line on purpose: the CPL logits of a lane are fetched together, the CPL exponentials
+    // are independent chains the scheduler can interleave, invalid class slots are multiplied by 0
+    // instead of being branched around.
+    int nk = 0;      // survivors so far (wave-uniform)
+    int ncand = 0;   // per-class candidates parked in s_key (wave-uniform)
+    for (int t0 = 0; t0 < npass; t0 += 4) {
+      const int slot = t0 + grp;
+      const bool act = slot < npass;
+      const int2 ent = s_list[min(slot, npass - 1)];
+      const int al = ent.x;
+      const float ma = __int_as_float(ent.y);
+      const float* r = tile + al * p.stride;
+      float e[CPL];
+#pragma unroll
+      for (int i = 0; i < CPL; ++i) e[i] = r[cidx[i]];
+#pragma unroll
+      for (int i = 0; i < CPL; ++i) e[i] = yp_exp_le0(e[i] - ma) * okf[i];   // x <= row max; 0 for c >= C
+      float s = e[0];                                                        // s_j = e_j + e_{j+16} + ...
+#pragma unroll
+      for (int i = 1; i < CPL; ++i) s = s + e[i];
+      float em = j > 0 ? e[0] : 0.0f;                        // class 0 is background (detection.py:59)
+#pragma unroll
+      for (int i = 1; i < CPL; ++i) em = max_nonneg(em, e[i]);   // e >= 0: integer max on the bit patterns
+      const float S = grp16_sum(s);
+      em = grp16_max_nonneg(em);
+      // IEEE division is monotone, so max_c fl(e_c/S) = fl(max_c e_c / S)              (detection.py:62)
+      const float pmax = em / S;
+      const bool surv = act && (pmax > p.conf);                                      // detection.py:73
+      const bool lead = surv && j == 0;
+      const u64 bl = __ballot(lead);
+      if (MODE == YP_NMS_CROSS_CLASS) {
+        // tf.argmax over the probabilities (detection.py:184): the FIRST class whose rounded
+        // probability equals the maximum.  Only an e_c within 2^-21 of the largest can round to it;
+        // almost always that is one class, found without any division.
         const float ethr = em * (1.0f - 0x1p-21f);
+        int cnt = 0, cmin = 0x7fffffff;
 #pragma unroll
         for (int i = 0; i < CPL; ++i) {
-          const int c = j + 16 * i;
-          if (c >= 1 && c < C && e[i] >= ethr) {
-            if (e[i] / S == pmax) arg = min(arg, c);
+          const bool hit = (e[i] >= ethr) && (i > 0 || j > 0);
+          cnt += hit ? 1 : 0;
+          cmin = hit ? min(cmin, j + 16 * i) : cmin;
+        }
+        cnt = grp16_sum_i(cnt);
+        int arg = grp16_min(cmin);
+        if (__ballot(surv && cnt > 1)) {   // rare: several classes within 2^-21 -> exact test
+          int a2 = 0x7fffffff;
+#pragma unroll
+          for (int i = 0; i < CPL; ++i) {
+            const bool hit = (e[i] >= ethr) && (i > 0 || j > 0);
+            if (hit && (e[i] / S == pmax)) a2 = min(a2, j + 16 * i);
+          }
+          a2 = grp16_min(a2);
+          if (cnt > 1) arg = a2;
+        }
+        if (lead) s_key[nk + __popcll(bl & lt_mask)] = yp_seg_key(pmax, a0 + al, arg);
+      } else {
+        // per-class candidates: every (anchor, class) with p > conf                 (detection.py:233)
+        // They are parked in LDS and appended to the per-class lists 64 at a time, so that the
+        // returning atomics of a whole tile are in flight together instead of one after another.
+        const float elo = S * p.conf_lo;
+        int nhit = 0, csel = 0;
+        float esel = 0.0f;
+#pragma unroll
+        for (int i = CPL - 1; i >= 0; --i) {
+          const bool hit = surv && (e[i] >= elo) && (i > 0 || j > 0);
+          nhit += hit ? 1 : 0;
+          csel = hit ? j + 16 * i : csel;
+          esel = hit ? e[i] : esel;
+        }
+        if (__ballot(nhit > 1) == 0) {
+          // common: at most one class per lane
+          const float pc = esel / S;
+          const bool has = (nhit == 1) && (pc > p.conf);
+          const u64 bm = __ballot(has);
+          if (has) s_key[ncand + __popcll(bm & lt_mask)] = yp_seg_key(pc, a0 + al, csel);
+          ncand += __popcll(bm);
+        } else {
+#pragma unroll
+          for (int i = 0; i < CPL; ++i) {
+            bool has = false;
+            float pc = 0.0f;
+            if (surv && (e[i] >= elo) && (i > 0 || j > 0)) {
+              pc = e[i] / S;
+              has = pc > p.conf;
+            }
+            const u64 bm = __ballot(has);
+            if (bm) {
+              if (ncand + __popcll(bm) > KCAP) {   // wave-uniform, rare: flush first
+                __builtin_amdgcn_wave_barrier();
+                for (int l0 = 0; l0 < ncand; l0 += YP_WAVE) {
+                  const int l = l0 + lane;
+                  if (l < ncand) {
+                    const u64 key = s_key[l];
+                    const size_t seg = (size_t)b * p.nseg + (yp_seg_key_class(key) - 1);
+                    const int qpos = atomicAdd(&p.cand_count[seg], 1);
+                    p.cand[seg * p.A + qpos] = key;
+                  }
+                }
+                nst = 100;   // unknown mix of atomics and stores in flight: next wait drains everything
+                __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): s_key is rewritten below
+                ncand = 0;
+              }
+              if (has) s_key[ncand + __popcll(bm & lt_mask)] = yp_seg_key(pc, a0 + al, j + 16 * i);
+              ncand += __popcll(bm);
+            }
           }
         }
-      }
-      arg = grp16_min(arg);
-      if (lead) s_key[pos] = yp_seg_key(pmax, a0 + al, arg);
-    } else {
-      // per-class candidates: every (anchor, class) with p > conf                   (detection.py:233)
-      // They are parked in LDS and appended to the per-class lists 64 at a time, so that the
-      // returning atomics of a whole tile are in flight together instead of one after another.
-      const float elo = S * p.conf_lo;
-#pragma unroll
-      for (int i = 0; i < CPL; ++i) {
-        const int c = j + 16 * i;
-        bool has = false;
-        float pc = 0.0f;
-        if (surv && c >= 1 && c < C && e[i] >= elo) {
-          pc = e[i] / S;
-          has = pc > p.conf;
-        }
-        const u64 bm = __ballot(has);
-        if (bm) {
-          if (has) s_key[ncand + __popcll(bm & lt_mask)] = yp_seg_key(pc, a0 + al, c);
-          ncand += __popcll(bm);
-          if (ncand > KCAP - YP_WAVE) {   // wave-uniform
-            __syncthreads();
-            for (int l = lane; l < ncand; l += YP_WAVE) {
+        if (ncand > KCAP - YP_WAVE) {   // keep room for the next round's fast path (<= 64 keys)
+          __builtin_amdgcn_wave_barrier();
+          for (int l0 = 0; l0 < ncand; l0 += YP_WAVE) {
+            const int l = l0 + lane;
+            if (l < ncand) {
               const u64 key = s_key[l];
               const size_t seg = (size_t)b * p.nseg + (yp_seg_key_class(key) - 1);
               const int qpos = atomicAdd(&p.cand_count[seg], 1);
               p.cand[seg * p.A + qpos] = key;
             }
-            __syncthreads();
-            ncand = 0;
           }
+          nst = 100;
+          __builtin_amdgcn_s_waitcnt(0xC07F);
+          ncand = 0;
         }
       }
+      nk += __popcll(bl);
     }
-    nk += __popcll(bl);
-  }
-  if (lane == 0) p.tile_count[(size_t)b * p.ntiles + blockIdx.x] = (p.ablate & 1) ? 0 : nk;
-  if (nk == 0 || (p.ablate & 1)) return;
-  __syncthreads();
 
-  // ---- phase 3: survivors ---------------------------------------------------------------------
-  if (MODE == YP_NMS_CROSS_CLASS) {
-    if (lane < nk) p.cand[((size_t)b * p.ntiles + blockIdx.x) * TA + lane] = s_key[lane];
-  } else {
-    for (int l = lane; l < ncand; l += YP_WAVE) {
-      const u64 key = s_key[l];
-      const size_t seg = (size_t)b * p.nseg + (yp_seg_key_class(key) - 1);
-      const int qpos = atomicAdd(&p.cand_count[seg], 1);
-      p.cand[seg * p.A + qpos] = key;
+    STAMP(T4);
+    // ---- phase 3: survivors (stores are never waited for inside the loop) -----------------------
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) p.tile_count[flat] = nk;
+    nst += 1;
+    if (MODE == YP_NMS_CROSS_CLASS) {
+      // always issued (lane 0 writes an ignored slot when nk == 0) so that `nst` is exact
+      if (lane < max(nk, 1)) p.cand[(size_t)flat * TA + lane] = s_key[lane];
+      nst += 1;
+    } else {
+      for (int l0 = 0; l0 < ncand; l0 += YP_WAVE) {
+        const int l = l0 + lane;
+        if (l < ncand) {
+          const u64 key = s_key[l];
+          const size_t seg = (size_t)b * p.nseg + (yp_seg_key_class(key) - 1);
+          const int qpos = atomicAdd(&p.cand_count[seg], 1);   // the compiler drains vmcnt for qpos
+          p.cand[seg * p.A + qpos] = key;
+        }
+      }
+      // the returning atomics above forced a full drain before their stores; only those stores
+      // (one instruction per started batch of 64) and nothing older can still be in flight,
+      // unless there was no candidate at all
+      nst = ncand > 0 ? (ncand + YP_WAVE - 1) / YP_WAVE : nst;
     }
-  }
+    // LDS reads of this tile must have returned before the DMA issued at the top of the next
+    // iteration overwrites the other buffer's successor; lgkmcnt(0) only.
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_wave_barrier();
+#ifdef YP_SF_STAMPS
+    { const long long T5 = clock64(); long long T1x = T0; if (p.fast) T1x = T2; (void)T1x;
+      dd[0] += T2 - T0; dd[2] += T3 - T2; dd[3] += T4 - T3; dd[4] += T5 - T4; dd[5] += 1; dd[6] += npass; }
+#endif
+  }   // tile loop
+#ifdef YP_SF_STAMPS
+  if (p.dbg && lane == 0) { unsigned long long* o = p.dbg + (size_t)blockIdx.x * 8; for (int i = 0; i < 8; ++i) o[i] = dd[i]; }
+#endif
 }
 
 template <int MODE, int TA>
-static void launch_mode(int cpl, int A, int batch, size_t lds, hipStream_t st, const ScoreFilterArgs& a) {
-  const dim3 grid((A + TA - 1) / TA, batch);
+static void launch_mode(int cpl, int nblocks, size_t lds, hipStream_t st, const ScoreFilterArgs& a) {
+  const dim3 grid(nblocks);
 #define YP_SF_CASE(N) case N: hipLaunchKernelGGL((score_filter_kernel<MODE, N, TA>), grid, dim3(YP_WAVE), lds, st, a); break;
   switch (cpl) {
     YP_SF_CASE(1) YP_SF_CASE(2) YP_SF_CASE(3) YP_SF_CASE(4) YP_SF_CASE(5) YP_SF_CASE(6)
@@ -249,15 +452,27 @@ hipError_t yp_launch_score_filter(const yp_handle* h, int batch, const float* pr
   a.conf = h->cfg.conf_thresh;
   a.conf_lo = h->cfg.conf_thresh * (1.0f - 0x1p-20f);
   a.pre_thresh = h->pre_thresh;
-  a.ablate = getenv("YP_ABLATE") ? atoi(getenv("YP_ABLATE")) : 0;
   const int TA = h->tile_anchors;
-  a.ntiles = h->ntiles;
-  const size_t lds = (size_t)TA * a.stride * sizeof(float) + YP_WAVE * sizeof(int) + 128 * sizeof(u64);
+  a.ntiles = h->ntiles; a.batch = batch;
+  a.ndma = h->sf_ndma; a.bufb = h->sf_bufb;
+#ifdef YP_SF_STAMPS
+  a.dbg = (unsigned long long*)h->dbg;
+  a.ablate = getenv("YP_ABLATE") ? atoi(getenv("YP_ABLATE")) : 0;
+#endif
+  a.fast = (a.stride == a.C) && (((long long)a.A * a.C) % 4 == 0) && ((((uintptr_t)pred_cls) & 15u) == 0) &&
+           ((long long)batch * a.A * a.C / 4 < 0x7fffffffLL);
+  const size_t lds = 2 * (size_t)a.bufb + YP_WAVE * sizeof(int2) + 128 * sizeof(u64);
   int cpl = (a.C + 15) / 16;                       // classes per lane in phase 2
   if (cpl == 7) cpl = 8; else if (cpl > 8 && cpl <= 12) cpl = 12; else if (cpl > 12) cpl = 16;
+  // persistent grid: as many single-wave workgroups as the LDS lets the chip hold
+  const int total_tiles = batch * h->ntiles;
+  int per_cu = (int)((160 * 1024) / lds);
+  per_cu = per_cu < 1 ? 1 : (per_cu > 16 ? 16 : per_cu);
+  const int wpc = getenv("YP_SF_WAVES_PER_CU") ? atoi(getenv("YP_SF_WAVES_PER_CU")) : per_cu;
+  const int nblocks = total_tiles < h->num_cus * wpc ? total_tiles : h->num_cus * wpc;
   const bool cc = h->cfg.nms_mode == YP_NMS_CROSS_CLASS;
-  if (TA == 64) { if (cc) launch_mode<YP_NMS_CROSS_CLASS, 64>(cpl, a.A, batch, lds, st, a); else launch_mode<YP_NMS_PER_CLASS, 64>(cpl, a.A, batch, lds, st, a); }
-  else if (TA == 32) { if (cc) launch_mode<YP_NMS_CROSS_CLASS, 32>(cpl, a.A, batch, lds, st, a); else launch_mode<YP_NMS_PER_CLASS, 32>(cpl, a.A, batch, lds, st, a); }
-  else { if (cc) launch_mode<YP_NMS_CROSS_CLASS, 16>(cpl, a.A, batch, lds, st, a); else launch_mode<YP_NMS_PER_CLASS, 16>(cpl, a.A, batch, lds, st, a); }
+  if (TA == 64) { if (cc) launch_mode<YP_NMS_CROSS_CLASS, 64>(cpl, nblocks, lds, st, a); else launch_mode<YP_NMS_PER_CLASS, 64>(cpl, nblocks, lds, st, a); }
+  else if (TA == 32) { if (cc) launch_mode<YP_NMS_CROSS_CLASS, 32>(cpl, nblocks, lds, st, a); else launch_mode<YP_NMS_PER_CLASS, 32>(cpl, nblocks, lds, st, a); }
+  else { if (cc) launch_mode<YP_NMS_CROSS_CLASS, 16>(cpl, nblocks, lds, st, a); else launch_mode<YP_NMS_PER_CLASS, 16>(cpl, nblocks, lds, st, a); }
   return hipGetLastError();
 }
