@@ -57,8 +57,10 @@ def main():
     ap.add_argument("--batch", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=16)
-    ap.add_argument("--timed-events", type=int, default=1,
-                    help="1: the timed region records the per-kernel HIP events too; 0: no events there")
+    ap.add_argument("--timed-events", type=int, default=0,
+                    help="1: the timed region records the per-kernel HIP events too (costs ~4%%); "
+                         "0 (default): `value` is timed without events and the same K steps are then "
+                         "repeated with events for the per-kernel durations")
     args = ap.parse_args()
 
     import torch
@@ -119,11 +121,15 @@ def main():
     # this region is NOT the one `value` comes from; the kernels themselves are identical).
     pp.profile(True)
     acc = {}
-    nprof = min(args.steps, 50)
+    nprof = args.steps
+    barrier()
+    t2 = time.perf_counter()
     for _ in range(nprof):
         pp.run(*ins, out=out)
         for k, v in pp.kernel_times_ms().items():
             acc[k] = acc.get(k, 0.0) + v
+    barrier()
+    ms_per_step_events = (time.perf_counter() - t2) / nprof * 1e3
     kern_ms = {k: v / nprof for k, v in acc.items()}
 
     S = pp.last_survivors(B)
@@ -162,6 +168,7 @@ def main():
             "bytes_per_launch": kb[dominant], "avg_launch_ms": round(kern_ms[dominant], 5),
         },
         "kernels_ms": {k: round(v, 5) for k, v in kern_ms.items()},
+        "ms_per_step_with_events": round(ms_per_step_events, 4),
         "kernels_gbs": {k: round(kb[k] / (kern_ms[k] * 1e-3) / 1e9, 1) if kern_ms[k] > 0 else 0.0 for k in kern_ms},
         "pipeline": {
             "bytes_per_step": total_bytes,
@@ -170,6 +177,14 @@ def main():
         },
     }
 
+    # HBM bytes per launch from the PMC passes of the same command (tools/gpu_profile.sh), if committed
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
+        key = f"{args.nms_mode}:{dominant}"
+        if args.config == 2 and B == cfg.batch and key in tj:
+            result["roofline"]["traffic"] = tj[key]
+    except Exception:
+        pass
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(net, shp, cfg, args)
     if rank == 0:

@@ -23,7 +23,6 @@ struct ScoreFilterArgs {
   int fast;              // 1: stride == C and every tile starts 16-byte aligned -> LDS-DMA path
 #ifdef YP_SF_STAMPS
   unsigned long long* dbg;   // diagnostic build only: per-wave phase cycle sums
-  int ablate;
 #endif
   float conf, conf_lo;
   float pre_thresh;      // ln(1/conf - 1) + 1e-3: x_bg - x_fgmax must be below it to have p_fgmax > conf
@@ -196,6 +195,7 @@ __global__ __launch_bounds__(YP_WAVE) void score_filter_kernel(const ScoreFilter
   if (p.fast) issue_dma(b, tix, 0u);
   advance(nb, ntix);
   int nst = 0;    // store instructions issued since the last DMA issue (wave-uniform)
+  int pend_flat = -1, pend_nk = 0;   // cross-class mode: tile whose outputs are still to be stored
 #ifdef YP_SF_STAMPS
   long long dd[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define STAMP(v) const long long v = clock64()
@@ -217,6 +217,11 @@ __global__ __launch_bounds__(YP_WAVE) void score_filter_kernel(const ScoreFilter
 #endif
       if (flat + G < total_tiles) issue_dma(nb, ntix, par ? 0u : (uint32_t)p.bufb);
       nst = 0;
+      if (MODE == YP_NMS_CROSS_CLASS && pend_flat >= 0) {   // previous tile's outputs (s_key is rewritten only in phase 2)
+        if (lane == 0) p.tile_count[pend_flat] = pend_nk;
+        if (lane < max(pend_nk, 1)) p.cand[(size_t)pend_flat * TA + lane] = s_key[lane];
+        nst = 2;
+      }
     } else {
       const int nelem = na * C;
       const float* __restrict__ src = p.cls + ((size_t)b * p.A + a0) * C;
@@ -259,11 +264,7 @@ __global__ __launch_bounds__(YP_WAVE) void score_filter_kernel(const ScoreFilter
       pre = (al1 < na) && (q == 0) && ((x0 - xf) < p.pre_thresh);
     }
     const u64 pm = __ballot(pre);
-#ifdef YP_SF_STAMPS
-    const int npass = p.ablate == 2 ? 0 : __popcll(pm);
-#else
     const int npass = __popcll(pm);
-#endif
     if (pre) s_list[__popcll(pm & lt_mask)] = make_int2(al1, __float_as_int(m));   // (tile-local anchor, row max)
     __builtin_amdgcn_wave_barrier();   // single wave: LDS operations execute in order
 
@@ -396,28 +397,35 @@ __global__ __launch_bounds__(YP_WAVE) void score_filter_kernel(const ScoreFilter
     }
 
     STAMP(T4);
-    // ---- phase 3: survivors (stores are never waited for inside the loop) -----------------------
+    // ---- phase 3: survivors ---------------------------------------------------------------------
     __builtin_amdgcn_wave_barrier();
-    if (lane == 0) p.tile_count[flat] = nk;
-    nst += 1;
-    if (MODE == YP_NMS_CROSS_CLASS) {
-      // always issued (lane 0 writes an ignored slot when nk == 0) so that `nst` is exact
-      if (lane < max(nk, 1)) p.cand[(size_t)flat * TA + lane] = s_key[lane];
-      nst += 1;
+    if (MODE == YP_NMS_CROSS_CLASS && p.fast) {
+      // deferred: the two stores are issued right AFTER the next iteration's DMA issue, so that they
+      // never sit in front of it in this wave's in-order vector-memory queue
+      pend_flat = flat;
+      pend_nk = nk;
     } else {
-      for (int l0 = 0; l0 < ncand; l0 += YP_WAVE) {
-        const int l = l0 + lane;
-        if (l < ncand) {
-          const u64 key = s_key[l];
-          const size_t seg = (size_t)b * p.nseg + (yp_seg_key_class(key) - 1);
-          const int qpos = atomicAdd(&p.cand_count[seg], 1);   // the compiler drains vmcnt for qpos
-          p.cand[seg * p.A + qpos] = key;
+      if (lane == 0) p.tile_count[flat] = nk;
+      nst += 1;
+      if (MODE == YP_NMS_CROSS_CLASS) {
+        // always issued (lane 0 writes an ignored slot when nk == 0) so that `nst` is exact
+        if (lane < max(nk, 1)) p.cand[(size_t)flat * TA + lane] = s_key[lane];
+        nst += 1;
+      } else {
+        for (int l0 = 0; l0 < ncand; l0 += YP_WAVE) {
+          const int l = l0 + lane;
+          if (l < ncand) {
+            const u64 key = s_key[l];
+            const size_t seg = (size_t)b * p.nseg + (yp_seg_key_class(key) - 1);
+            const int qpos = atomicAdd(&p.cand_count[seg], 1);   // the compiler drains vmcnt for qpos
+            p.cand[seg * p.A + qpos] = key;
+          }
         }
+        // the returning atomics above forced a full drain before their stores; only those stores
+        // (one instruction per started batch of 64) and nothing older can still be in flight,
+        // unless there was no candidate at all
+        nst = ncand > 0 ? (ncand + YP_WAVE - 1) / YP_WAVE : nst;
       }
-      // the returning atomics above forced a full drain before their stores; only those stores
-      // (one instruction per started batch of 64) and nothing older can still be in flight,
-      // unless there was no candidate at all
-      nst = ncand > 0 ? (ncand + YP_WAVE - 1) / YP_WAVE : nst;
     }
     // LDS reads of this tile must have returned before the DMA issued at the top of the next
     // iteration overwrites the other buffer's successor; lgkmcnt(0) only.
@@ -428,6 +436,10 @@ __global__ __launch_bounds__(YP_WAVE) void score_filter_kernel(const ScoreFilter
       dd[0] += T2 - T0; dd[2] += T3 - T2; dd[3] += T4 - T3; dd[4] += T5 - T4; dd[5] += 1; dd[6] += npass; }
 #endif
   }   // tile loop
+  if (MODE == YP_NMS_CROSS_CLASS && pend_flat >= 0) {
+    if (lane == 0) p.tile_count[pend_flat] = pend_nk;
+    if (lane < pend_nk) p.cand[(size_t)pend_flat * TA + lane] = s_key[lane];
+  }
 #ifdef YP_SF_STAMPS
   if (p.dbg && lane == 0) { unsigned long long* o = p.dbg + (size_t)blockIdx.x * 8; for (int i = 0; i < 8; ++i) o[i] = dd[i]; }
 #endif
@@ -457,16 +469,18 @@ hipError_t yp_launch_score_filter(const yp_handle* h, int batch, const float* pr
   a.ndma = h->sf_ndma; a.bufb = h->sf_bufb;
 #ifdef YP_SF_STAMPS
   a.dbg = (unsigned long long*)h->dbg;
-  a.ablate = getenv("YP_ABLATE") ? atoi(getenv("YP_ABLATE")) : 0;
 #endif
-  a.fast = (a.stride == a.C) && (((long long)a.A * a.C) % 4 == 0) && ((((uintptr_t)pred_cls) & 15u) == 0) &&
-           ((long long)batch * a.A * a.C / 4 < 0x7fffffffLL);
+  const bool fast_ok = (a.stride == a.C) && (((long long)a.A * a.C) % 4 == 0) && ((((uintptr_t)pred_cls) & 15u) == 0) &&
+                       ((long long)batch * a.A * a.C / 4 < 0x7fffffffLL);
+  a.fast = fast_ok ? 1 : 0;
   const size_t lds = 2 * (size_t)a.bufb + YP_WAVE * sizeof(int2) + 128 * sizeof(u64);
   int cpl = (a.C + 15) / 16;                       // classes per lane in phase 2
   if (cpl == 7) cpl = 8; else if (cpl > 8 && cpl <= 12) cpl = 12; else if (cpl > 12) cpl = 16;
   // persistent grid: as many single-wave workgroups as the LDS lets the chip hold
   const int total_tiles = batch * h->ntiles;
-  int per_cu = (int)((160 * 1024) / lds);
+  // (measured on MI355X: single-wave workgroups become co-resident up to ~128-140 KiB of LDS per CU,
+  //  one or two fewer than the occupancy API reports; an over-subscribed persistent grid runs in two rounds)
+  int per_cu = (int)((128 * 1024) / lds);
   per_cu = per_cu < 1 ? 1 : (per_cu > 16 ? 16 : per_cu);
   const int wpc = getenv("YP_SF_WAVES_PER_CU") ? atoi(getenv("YP_SF_WAVES_PER_CU")) : per_cu;
   const int nblocks = total_tiles < h->num_cus * wpc ? total_tiles : h->num_cus * wpc;
