@@ -117,7 +117,7 @@ extern "C" int yp_create(const yp_config* cfg, yp_handle** out) {
   }
   (void)hipDeviceSynchronize();   // the counters are zero before any stream can run score_filter
 #ifdef YP_SF_STAMPS
-  (void)hipMalloc(&h->dbg, 64 * 65536); (void)hipMemset(h->dbg, 0, 64 * 65536);
+  (void)hipMalloc(&h->dbg, 2 * 64 * 65536); (void)hipMemset(h->dbg, 0, 2 * 64 * 65536);
 #endif
   *out = h;
   g_err[0] = 0;
@@ -137,6 +137,16 @@ extern "C" int yp_destroy(yp_handle* h) {
     free(all);
     const double n = d[5] ? (double)d[5] : 1.0;
     fprintf(stderr, "[yp stamps] tiles=%llu phase0(wait+issue)=%.0f of which wait=%.0f phase1=%.0f phase2=%.0f phase3=%.0f cycles/tile npass=%.2f\n", d[5], d[0]/n, d[1]/n, d[2]/n, d[3]/n, d[4]/n, d[6]/n);
+    {
+      unsigned long long* nm = (unsigned long long*)malloc(64 * 65536);
+      (void)hipMemcpy(nm, (char*)h->dbg + 64 * 65536, 64 * 65536, hipMemcpyDeviceToHost);
+      for (int part = 0; part < 2; ++part) {
+        unsigned long long dsum[8] = {0}; int cnt = 0;
+        for (int w = part * 32768; w < (part + 1) * 32768; ++w) if (nm[w * 8 + 7]) { ++cnt; for (int i = 0; i < 7; ++i) dsum[i] += nm[w * 8 + i]; }
+        if (cnt) fprintf(stderr, "[yp stamps] %s blocks=%d  t1=%.0f t2=%.0f t3=%.0f t4=%.0f t5=%.0f t6=%.0f cycles/block (cumulative from kernel entry) n=%.1f\n", part ? "final_select" : "segment_nms", cnt, dsum[0]/(double)cnt, dsum[1]/(double)cnt, dsum[2]/(double)cnt, dsum[3]/(double)cnt, dsum[4]/(double)cnt, dsum[5]/(double)cnt, dsum[6]/(double)cnt);
+      }
+      free(nm);
+    }
     (void)hipFree(h->dbg);
   }
 #endif

@@ -39,12 +39,27 @@ struct NmsArgs {
   int A, nseg, top_k, max_dets, sel_rows, ntiles, TA;
   float nms_thresh, img_h, img_w, proto_h, proto_w;
   int use_crop;
+#ifdef YP_SF_STAMPS
+  unsigned long long* dbg;
+#endif
 };
+#ifdef YP_SF_STAMPS
+#define NSTAMP(i) do { if (threadIdx.x == 0) dbgo[i] = (unsigned long long)(clock64() - T00); } while (0)
+#define NSTAMP_BEGIN(blk, nval) const long long T00 = clock64(); unsigned long long* dbgo = p.dbg + (size_t)(blk) * 8; 
+#define NSTAMP_END(nval) do { if (threadIdx.x == 0) { dbgo[6] = (unsigned long long)(nval); dbgo[7] = 1; } } while (0)
+#else
+#define NSTAMP(i)
+#define NSTAMP_BEGIN(blk, nval)
+#define NSTAMP_END(nval)
+#endif
 
 struct SelectShared {
-  u64 key[YP_SORT_MAX];
+  u64 key[YP_SORT_MAX];    // result: selected keys, sorted descending
+  u64 tmp[YP_SORT_MAX];    // selected keys before sorting
+  int rank[YP_SORT_MAX];
   int hist[YP_RADIX_BINS];
   int wtot[16];
+  u64 lo, hi;
   int sel, need, cnt, fill;
 };
 
@@ -106,115 +121,168 @@ __device__ int block_sum(int v, int* wtot) {   // wtot: >= THREADS/64 ints of LD
   return s;
 }
 
-// The k-th largest of n unique keys: on return every key with (key & mask) >= prefix is one of the
-// k largest, and exactly k keys satisfy it.  MSB-first, YP_RADIX_BITS bits per pass, 4 barriers per pass.
+// One histogram pass over the keys with (key & mask) == prefix, digit = (key >> shift) & dmask.
+// Finds the bin that holds the need-th largest of them: sh.sel = bin, sh.need = how many are still
+// to be taken inside that bin, sh.cnt = keys in that bin.  Four barriers.
 template <int THREADS, class Src>
-__device__ void radix_select(const Src& src, int k, SelectShared& sh, u64& prefix_out, u64& mask_out) {
+__device__ void hist_pass(const Src& src, u64 mask, u64 prefix, int shift, u64 dmask, int need, SelectShared& sh) {
   constexpr int BPT = YP_RADIX_BINS / THREADS;   // bins per thread
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+#pragma unroll
+  for (int i = 0; i < BPT; ++i) sh.hist[t * BPT + i] = 0;
+  __syncthreads();
+  src.template for_each<THREADS>([&](u64 key) {
+    if ((key & mask) == prefix) atomicAdd(&sh.hist[(int)((key >> shift) & dmask)], 1);
+  });
+  __syncthreads();
+  int loc[BPT];
+  int tsum = 0;
+#pragma unroll
+  for (int i = 0; i < BPT; ++i) { loc[i] = sh.hist[t * BPT + i]; tsum += loc[i]; }
+  int incl = tsum;   // -> sum over lanes >= lane of this wave
+  for (int o = 1; o < 64; o <<= 1) {
+    const int v = __shfl_down(incl, o);
+    if (lane + o < 64) incl += v;
+  }
+  if (lane == 0) sh.wtot[wave] = incl;
+  __syncthreads();
+  int above = incl - tsum;   // keys in higher bins
+  for (int w = wave + 1; w < THREADS / 64; ++w) above += sh.wtot[w];
+#pragma unroll
+  for (int i = BPT - 1; i >= 0; --i) {
+    if (above < need && need <= above + loc[i]) { sh.sel = t * BPT + i; sh.need = need - above; sh.cnt = loc[i]; }
+    above += loc[i];
+  }
+  __syncthreads();
+}
+
+// The k-th largest of n unique keys: on return every key with (key & mask) >= prefix is one of the
+// k largest, and exactly k keys satisfy it.  MSB-first, YP_RADIX_BITS bits per pass.
+template <int THREADS, class Src>
+__device__ void radix_select(const Src& src, int k, SelectShared& sh, u64& prefix_out, u64& mask_out) {
   u64 prefix = 0, mask = 0;
   int need = k;
   for (int hi = 64; hi > 0; hi -= YP_RADIX_BITS) {
     const int shift = hi >= YP_RADIX_BITS ? hi - YP_RADIX_BITS : 0;
     const int bits = hi - shift;
     const u64 dmask = (1ull << bits) - 1ull;
-#pragma unroll
-    for (int i = 0; i < BPT; ++i) sh.hist[t * BPT + i] = 0;
-    __syncthreads();
-    src.template for_each<THREADS>([&](u64 key) {
-      if ((key & mask) == prefix) atomicAdd(&sh.hist[(int)((key >> shift) & dmask)], 1);
-    });
-    __syncthreads();
-    int loc[BPT];
-    int tsum = 0;
-#pragma unroll
-    for (int i = 0; i < BPT; ++i) { loc[i] = sh.hist[t * BPT + i]; tsum += loc[i]; }
-    int incl = tsum;   // -> sum over lanes >= lane of this wave
-    for (int o = 1; o < 64; o <<= 1) {
-      const int v = __shfl_down(incl, o);
-      if (lane + o < 64) incl += v;
-    }
-    if (lane == 0) sh.wtot[wave] = incl;
-    __syncthreads();
-    int above = incl - tsum;   // keys in higher bins
-    for (int w = wave + 1; w < THREADS / 64; ++w) above += sh.wtot[w];
-#pragma unroll
-    for (int i = BPT - 1; i >= 0; --i) {
-      if (above < need && need <= above + loc[i]) { sh.sel = t * BPT + i; sh.need = need - above; sh.cnt = loc[i]; }
-      above += loc[i];
-    }
-    __syncthreads();
+    hist_pass<THREADS>(src, mask, prefix, shift, dmask, need, sh);
     prefix |= (u64)sh.sel << shift;
     mask |= dmask << shift;
     need = sh.need;
-    if (sh.cnt == need) break;   // every key left in the selected bin is taken (uniform decision)
+    const bool done = sh.cnt == need;   // every key left in the selected bin is taken (uniform decision)
+    __syncthreads();
+    if (done) break;
   }
   prefix_out = prefix;
   mask_out = mask;
 }
 
+// Sorts sh.tmp[0..m) (unique keys, m <= 256) descending into sh.key[0..m): the rank of a key is the
+// number of larger keys, counted with broadcast LDS reads - two barriers instead of a sorting network.
+// sh.rank[] must be zero on entry; it is left zero.
+template <int THREADS>
+__device__ void rank_sort_desc(SelectShared& sh, int m) {
+  constexpr int G = THREADS / YP_SORT_MAX;
+  const int t = threadIdx.x;
+  const int j = t % YP_SORT_MAX, g = t / YP_SORT_MAX;
+  u64 mine = 0;
+  if (j < m) {
+    mine = sh.tmp[j];
+    int c = 0;
+    for (int i = g; i < m; i += G) c += sh.tmp[i] > mine ? 1 : 0;
+    if (G == 1) sh.rank[j] = c;
+    else if (c) atomicAdd(&sh.rank[j], c);
+  }
+  __syncthreads();
+  if (t < m) {
+    sh.key[sh.rank[t]] = mine;
+    sh.rank[t] = 0;
+  }
+  __syncthreads();
+}
+
+__device__ __forceinline__ u64 wave_min_u64(u64 v) {
+  for (int o = 32; o > 0; o >>= 1) { const u64 w = __shfl_xor(v, o); v = w < v ? w : v; }
+  return v;
+}
+__device__ __forceinline__ u64 wave_max_u64(u64 v) {
+  for (int o = 32; o > 0; o >>= 1) { const u64 w = __shfl_xor(v, o); v = w > v ? w : v; }
+  return v;
+}
+
 // Leaves the k = min(want, n) largest keys of src in sh.key[0..k), descending; returns k.
 // All threads of the workgroup must call it.  Keys are unique and non-zero.  `stage` is an optional
 // LDS buffer of YP_STAGE_CAP keys.
+//   n <= 256: everything is rank-sorted.
+//   else: ONE histogram pass over the 11 bits just below the highest bit in which the keys differ
+//   (found from their min and max) isolates the bin of the k-th key; if the keys above that bin plus
+//   the bin itself are <= 256 (the normal case: the bins are narrow) they are rank-sorted and the
+//   first k are the answer.  Otherwise a full MSB-first radix select runs.
 template <int THREADS, class Src>
 __device__ int select_topk_sorted(const Src& src, int n, int want, SelectShared& sh, u64* stage) {
   const int t = threadIdx.x;
   const int k = min(want, n);
-  if (t == 0) sh.fill = 0;
-  if (t < YP_SORT_MAX) sh.key[t] = 0ull;
+  if (t == 0) { sh.fill = 0; sh.lo = ~0ull; sh.hi = 0ull; }
+  if (t < YP_SORT_MAX) sh.rank[t] = 0;
   __syncthreads();
   int m;
   if (n <= YP_SORT_MAX) {
     src.template for_each<THREADS>([&](u64 key) {
       const int q = atomicAdd(&sh.fill, 1);
-      if (q < YP_SORT_MAX) sh.key[q] = key;
+      if (q < YP_SORT_MAX) sh.tmp[q] = key;
     });
     m = n;
-  } else if (stage != nullptr && n <= YP_STAGE_CAP) {
+  } else {
+    const bool staged = stage != nullptr && n <= YP_STAGE_CAP;
+    u64 lo = ~0ull, hi = 0ull;
     src.template for_each<THREADS>([&](u64 key) {
-      const int q = atomicAdd(&sh.fill, 1);
-      if (q < YP_STAGE_CAP) stage[q] = key;
+      lo = key < lo ? key : lo;
+      hi = key > hi ? key : hi;
+      if (staged) {
+        const int q = atomicAdd(&sh.fill, 1);
+        if (q < YP_STAGE_CAP) stage[q] = key;
+      }
     });
+    lo = wave_min_u64(lo);
+    hi = wave_max_u64(hi);
+    if ((t & 63) == 0) { atomicMin(&sh.lo, lo); atomicMax(&sh.hi, hi); }
     __syncthreads();
     if (t == 0) sh.fill = 0;
+    const u64 diff = sh.lo ^ sh.hi;                         // != 0: more than one distinct key
+    const int top = 63 - __clzll((long long)diff);          // highest bit in which keys differ
+    const int shift = top >= YP_RADIX_BITS ? top - (YP_RADIX_BITS - 1) : 0;
+    const u64 dmask = (1ull << (top - shift + 1)) - 1ull;
     const ListSrc ls{stage, n};
-    u64 prefix, mask;
-    radix_select<THREADS>(ls, k, sh, prefix, mask);
-    ls.template for_each<THREADS>([&](u64 key) {
-      if ((key & mask) >= prefix) {
-        const int q = atomicAdd(&sh.fill, 1);
-        if (q < YP_SORT_MAX) sh.key[q] = key;
-      }
-    });
-    m = k;
-  } else {
-    u64 prefix, mask;
-    radix_select<THREADS>(src, k, sh, prefix, mask);
-    src.template for_each<THREADS>([&](u64 key) {
-      if ((key & mask) >= prefix) {
-        const int q = atomicAdd(&sh.fill, 1);
-        if (q < YP_SORT_MAX) sh.key[q] = key;
-      }
-    });
-    m = k;
-  }
-  __syncthreads();
-  // bitonic sort, descending, over the next power of two >= m
-  int sz = 1;
-  while (sz < m) sz <<= 1;
-  for (int k2 = 2; k2 <= sz; k2 <<= 1) {
-    for (int j = k2 >> 1; j > 0; j >>= 1) {
-      if (t < sz) {
-        const int ixj = t ^ j;
-        if (ixj > t) {
-          const u64 x = sh.key[t], y = sh.key[ixj];
-          const bool desc = (t & k2) == 0;
-          if (desc ? (x < y) : (x > y)) { sh.key[t] = y; sh.key[ixj] = x; }
+    if (staged) hist_pass<THREADS>(ls, 0ull, 0ull, shift, dmask, k, sh);   // bits above `top` are common
+    else hist_pass<THREADS>(src, 0ull, 0ull, shift, dmask, k, sh);
+    const int sel = sh.sel;
+    const int superset = (k - sh.need) + sh.cnt;            // keys in bins >= sel
+    if (superset <= YP_SORT_MAX) {
+      auto take = [&](u64 key) {
+        if ((int)((key >> shift) & dmask) >= sel) {
+          const int q = atomicAdd(&sh.fill, 1);
+          if (q < YP_SORT_MAX) sh.tmp[q] = key;
         }
-      }
+      };
+      if (staged) ls.template for_each<THREADS>(take); else src.template for_each<THREADS>(take);
+      m = superset;
+    } else {
       __syncthreads();
+      u64 prefix, mask;
+      if (staged) radix_select<THREADS>(ls, k, sh, prefix, mask); else radix_select<THREADS>(src, k, sh, prefix, mask);
+      auto take = [&](u64 key) {
+        if ((key & mask) >= prefix) {
+          const int q = atomicAdd(&sh.fill, 1);
+          if (q < YP_SORT_MAX) sh.tmp[q] = key;
+        }
+      };
+      if (staged) ls.template for_each<THREADS>(take); else src.template for_each<THREADS>(take);
+      m = k;
     }
   }
+  __syncthreads();
+  rank_sort_desc<THREADS>(sh, m);
   return k;
 }
 
@@ -267,18 +335,19 @@ __device__ void finish_image(const NmsArgs& p, int b, int n, const int* s_anchor
 
 // iou_max[j] = max_{i<j} iou(i,j) over the k sorted boxes in sbox; keep = iou_max <= thr, order
 // preserved (detection.py:190-202).  Returns this thread's keep flag (threads < k) and its rank
-// among the kept ones in `pos`; `total` = number kept.  All threads must call it.
+// among the kept ones in `pos`; `total` = number kept.  smax[] must be zero.  All threads must call it.
 template <int THREADS>
 __device__ bool fast_nms_keep(const float4* sbox, int* smax, int* s_wave_cnt, int k, float thr, int& pos, int& total) {
-  constexpr int G = THREADS / YP_SORT_MAX;
   const int t = threadIdx.x;
-  const int j = t % YP_SORT_MAX, g = t / YP_SORT_MAX;
+  int sz = 64;                       // columns rounded up to a power of two; the rest of the
+  while (sz < k) sz <<= 1;           // workgroup's threads split each column's rows
+  const int G = THREADS / sz;
+  const int j = t & (sz - 1), g = t / sz;
   if (j < k) {
     const float4 bj = sbox[j];
     float mx = 0.0f;   // +0.0f: the zeroed diagonal/lower triangle take part in reduce_max
     for (int i = g; i < j; i += G) mx = fmaxf(mx, yp_iou(sbox[i], bj));
-    if (G == 1) smax[j] = __float_as_int(mx);
-    else atomicMax(&smax[j], __float_as_int(mx));   // iou >= 0: int order == float order
+    if (mx > 0.0f) atomicMax(&smax[j], __float_as_int(mx));   // iou >= 0: int order == float order
   }
   __syncthreads();
   bool keep = false;
@@ -348,57 +417,51 @@ template <int THREADS>
 __global__ __launch_bounds__(THREADS) void class_nms_kernel(const NmsArgs p) {
   __shared__ SelectShared sh;
   __shared__ float4 sbox[YP_SORT_MAX];
-  __shared__ float4 sbox_u[YP_SORT_MAX];
   __shared__ int smax[YP_SORT_MAX];
   __shared__ int s_wave_cnt[YP_SORT_MAX / YP_WAVE];
   const int t = threadIdx.x;
   const int seg = blockIdx.x, b = blockIdx.y;
   const size_t sidx = (size_t)b * p.nseg + seg;
+  NSTAMP_BEGIN(sidx, 0)
   const u64* list = p.cand + sidx * p.A;
   // the count and (speculatively) the first 256 keys travel together
   const int n = min(p.cand_count[sidx], p.A);
   const u64 kspec = list[min(t, p.A - 1)];
   __syncthreads();
+  NSTAMP(0);
   if (t == 0) p.cand_count[sidx] = 0;   // leave the counter ready for the next run
   if (n == 0) {
     if (t == 0) p.pool_count[sidx] = 0;
     return;
   }
   int k;
+  if (t < YP_SORT_MAX) { smax[t] = 0; sh.rank[t] = 0; }
   if (n <= YP_SORT_MAX) {
-    // boxes are fetched before the sort; the key's class byte (implied by the segment) carries the
-    // slot number so that the sorted order can pick its box up from LDS
+    // Every candidate's box is fetched and decoded while its rank (= number of larger keys) is
+    // counted; key and box then go straight to their sorted position.
     const bool have = t < n;
+    float4 pr = make_float4(0.f, 0.f, 0.f, 0.f), of = pr;
     if (have) {
       const int a = min(yp_seg_key_anchor(kspec), p.A - 1);
-      sbox_u[t] = yp_decode(p.priors[a], p.off[(size_t)b * p.A + a]);                 // detection.py:79
+      pr = p.priors[a];
+      of = p.off[(size_t)b * p.A + a];
+      sh.tmp[t] = kspec;
     }
-    if (t < YP_SORT_MAX) sh.key[t] = have ? ((kspec & ~0xFFull) | (u64)t) : 0ull;
-    if (t < YP_SORT_MAX) smax[t] = 0;
     __syncthreads();
-    int sz = 1;
-    while (sz < n) sz <<= 1;
-    for (int k2 = 2; k2 <= sz; k2 <<= 1) {
-      for (int j = k2 >> 1; j > 0; j >>= 1) {
-        if (t < sz) {
-          const int ixj = t ^ j;
-          if (ixj > t) {
-            const u64 x = sh.key[t], y = sh.key[ixj];
-            const bool desc = (t & k2) == 0;
-            if (desc ? (x < y) : (x > y)) { sh.key[t] = y; sh.key[ixj] = x; }
-          }
-        }
-        __syncthreads();
-      }
+    NSTAMP(1);
+    if (have) {
+      int r = 0;
+      for (int i = 0; i < n; ++i) r += sh.tmp[i] > kspec ? 1 : 0;
+      sh.key[r] = kspec;
+      sbox[r] = yp_decode(pr, of);                                                      // detection.py:79
     }
     k = min(p.top_k, n);
-    if (t < k) sbox[t] = sbox_u[(int)(sh.key[t] & 0xFFull)];
     __syncthreads();
+    NSTAMP(2);
   } else {
     const ListSrc ls{list, n};
     k = select_topk_sorted<THREADS>(ls, n, p.top_k, sh, nullptr);                 // detection.py:217
     if (t < YP_SORT_MAX) {
-      smax[t] = 0;
       if (t < k) {                                                                      // detection.py:219
         const int a = min(yp_seg_key_anchor(sh.key[t]), p.A - 1);   // (clamp: never index out of bounds)
         sbox[t] = yp_decode(p.priors[a], p.off[(size_t)b * p.A + a]);
@@ -408,12 +471,15 @@ __global__ __launch_bounds__(THREADS) void class_nms_kernel(const NmsArgs p) {
   }
   int pos, total;
   const bool keep = fast_nms_keep<THREADS>(sbox, smax, s_wave_cnt, k, p.nms_thresh, pos, total);
+  NSTAMP(3);
   // class-major pool of survivors for the cross-class top-N               (detection.py:234-239)
   if (keep) {
     const u64 key = sh.key[t];
     p.pool[sidx * p.top_k + pos] = yp_fin_key(yp_key_score(key), yp_seg_key_anchor(key), seg + 1);
   }
   if (t == 0) p.pool_count[sidx] = total;
+  NSTAMP(4);
+  NSTAMP_END(n);
 }
 
 // Per-class mode only: cross-class top max_dets over the pooled survivors (detection.py:242-248).
@@ -424,6 +490,7 @@ __global__ __launch_bounds__(THREADS) void final_select_kernel(const NmsArgs p) 
   __shared__ int s_anchor[YP_SORT_MAX];
   const int t = threadIdx.x;
   const int b = blockIdx.x;
+  NSTAMP_BEGIN(32768 + b, 0)
   const int32_t* counts = p.pool_count + (size_t)b * p.nseg;
   int part = 0;
   for (int i = t; i < p.nseg; i += THREADS) part += counts[i];
@@ -431,10 +498,12 @@ __global__ __launch_bounds__(THREADS) void final_select_kernel(const NmsArgs p) 
   part = 0;
   for (int i = t; i < p.ntiles; i += THREADS) part += p.tile_count[(size_t)b * p.ntiles + i];
   const int survivors = block_sum<THREADS>(part, sh.wtot);
+  NSTAMP(0);
   int k = 0;
   if (n > 0) {
     const SlotSrc src{p.pool + (size_t)b * p.nseg * p.top_k, counts, p.nseg, p.top_k};
     k = select_topk_sorted<THREADS>(src, n, min(p.max_dets, YP_SORT_MAX), sh, stage);
+    NSTAMP(3);
     if (t < k) {
       const u64 key = sh.key[t];
       const int anchor = min(yp_fin_key_anchor(key), p.A - 1);
@@ -443,8 +512,11 @@ __global__ __launch_bounds__(THREADS) void final_select_kernel(const NmsArgs p) 
                yp_decode(p.priors[anchor], p.off[(size_t)b * p.A + anchor]));
     }
     __syncthreads();
+    NSTAMP(4);
   }
   finish_image<THREADS>(p, b, k, s_anchor, survivors);
+  NSTAMP(5);
+  NSTAMP_END(n);
 }
 
 static NmsArgs make_args(const yp_handle* h, const float* pred_offset, const float* priors, const float* pred_mask_coef, float* det_boxes, float* det_classes,
@@ -462,6 +534,9 @@ static NmsArgs make_args(const yp_handle* h, const float* pred_offset, const flo
   a.img_h = (float)h->cfg.img_h; a.img_w = (float)h->cfg.img_w;
   a.proto_h = (float)h->cfg.proto_h; a.proto_w = (float)h->cfg.proto_w;
   a.use_crop = h->cfg.use_cropped_mask;
+#ifdef YP_SF_STAMPS
+  a.dbg = (unsigned long long*)((char*)h->dbg + 64 * 65536);
+#endif
   return a;
 }
 
