@@ -102,6 +102,8 @@ def main():
     for _ in range(args.warmup):
         pp.run(*ins, out=out)
     barrier()
+    if os.environ.get("YP_SF_ABL_AFTER_WARMUP"):   # diagnostic builds only (tools/sf_ablate.sh)
+        os.environ["YP_SF_ABL"] = os.environ["YP_SF_ABL_AFTER_WARMUP"]
     kern_ms = {}
     t0 = time.perf_counter()
     for _ in range(args.steps):

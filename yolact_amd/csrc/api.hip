@@ -9,6 +9,8 @@
 #include <new>
 
 #include "common.hpp"
+#include <vector>
+#include <algorithm>
 
 static thread_local char g_err[512] = "";
 
@@ -75,13 +77,21 @@ extern "C" int yp_create(const yp_config* cfg, yp_handle** out) {
     const int v = atoi(ev);
     if (v == 16 || v == 32 || v == 64) h->tile_anchors = v;
   }
-  for (;;) {   // two LDS tile buffers per wave must fit the 64 KiB a workgroup may take without opt-in
-    const int tile_bytes = h->tile_anchors * h->lds_stride * (int)sizeof(float);
-    h->sf_ndma = (h->tile_anchors * c.num_classes * (int)sizeof(float) + 1023) / 1024;
-    h->sf_bufb = h->sf_ndma * 1024 > tile_bytes ? h->sf_ndma * 1024 : (tile_bytes + 15) / 16 * 16;
-    if (2 * h->sf_bufb + 2048 <= 64 * 1024 || h->tile_anchors == 16) break;
+  h->sf_nbuf = 2;
+  if (const char* ev = getenv("YP_SF_NBUF")) {        // tuning knob for benchmarks
+    const int v = atoi(ev);
+    if (v == 2 || v == 3) h->sf_nbuf = v;
+  }
+  for (;;) {   // the LDS tile buffers of a wave must fit the 64 KiB a workgroup may take without opt-in
+    const int row_bytes = h->tile_anchors * h->lds_stride * (int)sizeof(float);
+    const int dma_bytes = h->tile_anchors * c.num_classes * (int)sizeof(float);   // multiple of 64
+    h->sf_ndma = dma_bytes / 1024;            // full 1 KiB LDS-DMA pieces ...
+    h->sf_rem = (dma_bytes % 1024) / 16;      // ... and the lanes of the last, partial one
+    h->sf_bufb = (row_bytes + 15) / 16 * 16;
+    if (h->sf_nbuf * h->sf_bufb + 2048 <= 64 * 1024 || h->tile_anchors == 16) break;
     h->tile_anchors /= 2;
   }
+  if (h->sf_nbuf * h->sf_bufb + 2048 > 64 * 1024) h->sf_nbuf = 2;
 
   h->ntiles = (c.num_anchors + h->tile_anchors - 1) / h->tile_anchors;
   const size_t B = (size_t)c.max_batch, A = (size_t)c.num_anchors, nseg = (size_t)h->nseg;
@@ -134,9 +144,18 @@ extern "C" int yp_destroy(yp_handle* h) {
     (void)hipMemcpy(all, h->dbg, 64 * 65536, hipMemcpyDeviceToHost);
     unsigned long long d[8] = {0};
     for (int w = 0; w < 65536; ++w) for (int i = 0; i < 7; ++i) d[i] += all[w * 8 + i];
+    {
+      std::vector<double> life, comp, tiles;
+      for (int w = 0; w < 65536; ++w) if (all[w * 8 + 5]) { life.push_back((double)all[w * 8 + 7]); comp.push_back((double)(all[w * 8 + 2] + all[w * 8 + 3])); tiles.push_back((double)all[w * 8 + 5]); }
+      auto pct = [](std::vector<double> v, const char* name) {
+        if (v.empty()) return; std::sort(v.begin(), v.end()); const size_t n = v.size();
+        fprintf(stderr, "[yp stamps] per-wave %s: n=%zu min=%.0f p10=%.0f p50=%.0f p90=%.0f max=%.0f\n", name, n, v[0], v[n / 10], v[n / 2], v[n * 9 / 10], v[n - 1]);
+      };
+      pct(life, "lifetime"); pct(comp, "phase1+2 cycles"); pct(tiles, "tiles");
+    }
     free(all);
     const double n = d[5] ? (double)d[5] : 1.0;
-    fprintf(stderr, "[yp stamps] tiles=%llu phase0(wait+issue)=%.0f of which wait=%.0f phase1=%.0f phase2=%.0f phase3=%.0f cycles/tile npass=%.2f\n", d[5], d[0]/n, d[1]/n, d[2]/n, d[3]/n, d[4]/n, d[6]/n);
+    fprintf(stderr, "[yp stamps] tiles=%llu phase0(wait+issue)=%.0f of which wait=%.0f phase1=%.0f phase2=%.0f dma_issue=%.0f cycles/tile npass=%.2f\n", d[5], d[0]/n, d[1]/n, d[2]/n, d[3]/n, d[4]/n, d[6]/n);
     {
       unsigned long long* nm = (unsigned long long*)malloc(64 * 65536);
       (void)hipMemcpy(nm, (char*)h->dbg + 64 * 65536, 64 * 65536, hipMemcpyDeviceToHost);

@@ -130,7 +130,8 @@ struct yp_handle {
   int tile_anchors;     // TA: anchors per score_filter wave (16, 32 or 64)
   int ntiles;           // ceil(A / TA)
   int num_cus;          // compute units of the device (256 on MI355X)
-  int sf_ndma, sf_bufb; // score_filter: LDS-DMA instructions per tile, bytes per LDS tile buffer
+  int sf_ndma, sf_rem;  // score_filter: full 1 KiB LDS-DMA pieces per tile + lanes of the partial last piece
+  int sf_bufb, sf_nbuf; // score_filter: bytes per LDS tile buffer, buffers per wave (prefetch distance + 1)
 #ifdef YP_SF_STAMPS
   void* dbg;            // diagnostic build only
 #endif

@@ -5,12 +5,12 @@
 // scatter of detection.py:113.
 //
 // HBM-bound by the N*4*P bytes of masks it writes per image (K=32 gives ~12 flop/byte, below the
-// ~25 flop/byte balance of 157 TFLOP/s fp32 over ~6.3 TB/s).  A lane owns PPL consecutive proto
-// pixels and keeps their 32 prototype values in VGPRs for the whole kernel, so the prototypes are
-// read from HBM exactly once; the coefficients and crop edges of detection n are wave-uniform and
-// come in through scalar loads.  The dot product is a K-ordered fma chain (YP-MATH) and is skipped
-// for waves whose 64*PPL pixels lie entirely outside detection n's crop box - those only store
-// zeros.  Output is written [N][P] (pixel-contiguous), which is the reference's final layout.
+// ~25 flop/byte balance of 157 TFLOP/s fp32 over ~6.3 TB/s).  A lane owns one proto pixel and
+// keeps its 32 prototype values in VGPRs for the whole kernel, so the prototypes are read from
+// HBM exactly once; the coefficients and crop edges of detection n are wave-uniform and come in
+// through scalar loads.  The dot product is a K-ordered fma chain (YP-MATH) and is skipped for
+// waves whose 64 pixels lie entirely outside detection n's crop box - those only store zeros.
+// Output is written [N][P] (pixel-contiguous), which is the reference's final layout.
 #include <stdlib.h>
 #include "common.hpp"
 
@@ -25,44 +25,58 @@ struct MaskArgs {
   float mask_threshold;
 };
 
-template <int PPL> struct VecT;
-template <> struct VecT<1> { typedef float type; };
-template <> struct VecT<2> { typedef float2 type; };
-template <> struct VecT<4> { typedef float4 type; };
+#define YP_MASK_BLOCK 256
+#define YP_MASK_ROW4 9   // float4 per pixel row in LDS: 8 of data + 1 of padding (144-byte stride)
 
-template <int PPL>
-__global__ __launch_bounds__(256) void mask_assemble_kernel(const MaskArgs p) {
-  const int b = blockIdx.y;
-  const int pix0 = (blockIdx.x * 256 + threadIdx.x) * PPL;
-  const bool live = pix0 < p.P;   // P % PPL == 0 is guaranteed by the launcher
+// One workgroup = 256 consecutive proto pixels of one image; a lane owns one pixel.
+//   1. the block's 256 x 32 prototype values (32 KiB, contiguous in HBM) are fetched with fully
+//      coalesced NON-TEMPORAL 16-byte loads (read once, by nobody else: they must not displace the
+//      output lines that live in L2 / Infinity Cache) and transposed through LDS, so that every lane
+//      ends up with its pixel's 32 values in VGPRs;
+//   2. loop over the image's detections: crop test, K-ordered fma chain + sigmoid for waves that
+//      touch the crop box, one coalesced 256-byte store per wave and detection.
+// Workgroups of one image are placed on one XCD (the dispatcher deals consecutive workgroup ids
+// round-robin over the 8 XCDs), so the partial cache lines at workgroup borders (mask rows are
+// only 16-byte aligned: P*4 bytes is not a multiple of 128) merge in a single L2.
+template <bool NT_STORE>
+__global__ __launch_bounds__(YP_MASK_BLOCK) void mask_assemble_kernel(const MaskArgs p, int blocks_per_image, int batch) {
+  __shared__ float4 sproto[YP_MASK_BLOCK * YP_MASK_ROW4];
+  typedef float nat4 __attribute__((ext_vector_type(4)));
+  const int t = threadIdx.x;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int b = (slot / blocks_per_image) * 8 + xcd;
+  if (b >= batch) return;
+  const int base_pix = (slot % blocks_per_image) * YP_MASK_BLOCK;
+  const int npx = min(YP_MASK_BLOCK, p.P - base_pix);
+  const int pix = base_pix + t;
+  const bool live = t < npx;
   const int N = min(p.num_det[b], p.sel_rows);
 
-  float pr[PPL][YP_MASK_DIM];
-  float frow[PPL], fcol[PPL];
-  if (live) {
-    const float4* src = reinterpret_cast<const float4*>(p.proto + ((size_t)b * p.P + pix0) * YP_MASK_DIM);
+  {
+    const nat4* src = reinterpret_cast<const nat4*>(p.proto + ((size_t)b * p.P + base_pix) * YP_MASK_DIM);
+    nat4 x[YP_MASK_DIM / 4];
 #pragma unroll
-    for (int q = 0; q < PPL; ++q) {
-#pragma unroll
-      for (int v = 0; v < YP_MASK_DIM / 4; ++v) {
-        const float4 x = src[q * (YP_MASK_DIM / 4) + v];
-        pr[q][4 * v + 0] = x.x; pr[q][4 * v + 1] = x.y; pr[q][4 * v + 2] = x.z; pr[q][4 * v + 3] = x.w;
-      }
-      const int pix = pix0 + q;
-      const int r = pix / p.pw;
-      frow[q] = (float)r;                  // tf.range(..., dtype=float32), utils/utils.py:119-120
-      fcol[q] = (float)(pix - r * p.pw);
+    for (int i = 0; i < YP_MASK_DIM / 4; ++i) {
+      const int idx = i * YP_MASK_BLOCK + t;
+      x[i] = __builtin_nontemporal_load(src + min(idx, npx * (YP_MASK_DIM / 4) - 1));
     }
-  } else {
 #pragma unroll
-    for (int q = 0; q < PPL; ++q) {
-      frow[q] = -1.0f; fcol[q] = -1.0f;
-#pragma unroll
-      for (int k = 0; k < YP_MASK_DIM; ++k) pr[q][k] = 0.0f;
+    for (int i = 0; i < YP_MASK_DIM / 4; ++i) {
+      const int idx = i * YP_MASK_BLOCK + t;
+      sproto[(idx >> 3) * YP_MASK_ROW4 + (idx & 7)] = make_float4(x[i].x, x[i].y, x[i].z, x[i].w);
     }
   }
+  __syncthreads();
+  float pr[YP_MASK_DIM];
+#pragma unroll
+  for (int v = 0; v < YP_MASK_DIM / 4; ++v) {
+    const float4 x = sproto[t * YP_MASK_ROW4 + v];
+    pr[4 * v + 0] = x.x; pr[4 * v + 1] = x.y; pr[4 * v + 2] = x.z; pr[4 * v + 3] = x.w;
+  }
+  const int r = pix / p.pw;
+  const float frow = live ? (float)r : -1.0f;                  // tf.range(..., dtype=float32), utils/utils.py:119-120
+  const float fcol = live ? (float)(pix - r * p.pw) : -1.0f;
 
-  typedef typename VecT<PPL>::type vec_t;
   float* const out_img = p.masks + (size_t)b * p.max_dets * p.P;
   uint8_t* const bit_img = p.bitmaps ? p.bitmaps + (size_t)b * p.max_dets * p.P : nullptr;
 
@@ -76,57 +90,27 @@ __global__ __launch_bounds__(256) void mask_assemble_kernel(const MaskArgs p) {
     float4 cb;
     cb.x = crop_c[4 * n + 0]; cb.y = crop_c[4 * n + 1]; cb.z = crop_c[4 * n + 2]; cb.w = crop_c[4 * n + 3];
     cfloat* const cf = coef_c + n * YP_MASK_DIM;
-    bool in[PPL];
-    bool any = false;
+    // mask_left & mask_right & mask_bottom & mask_top, float compares (utils/utils.py:125-130)
+    const bool in = live && (fcol >= cb.x) && (fcol < cb.y) && (frow >= cb.z) && (frow < cb.w);
+    float v = 0.0f;
+    if (__ballot(in)) {
+      float acc = 0.0f;
 #pragma unroll
-    for (int q = 0; q < PPL; ++q) {
-      // mask_left & mask_right & mask_bottom & mask_top, float compares (utils/utils.py:125-130)
-      in[q] = live && (fcol[q] >= cb.x) && (fcol[q] < cb.y) && (frow[q] >= cb.z) && (frow[q] < cb.w);
-      any = any || in[q];
-    }
-    float v[PPL];
-#pragma unroll
-    for (int q = 0; q < PPL; ++q) v[q] = 0.0f;
-    if (__ballot(any)) {
-      float acc[PPL];
-#pragma unroll
-      for (int q = 0; q < PPL; ++q) acc[q] = 0.0f;
-#pragma unroll
-      for (int k = 0; k < YP_MASK_DIM; ++k) {
-        const float c = cf[k];
-#pragma unroll
-        for (int q = 0; q < PPL; ++q) acc[q] = __builtin_fmaf(pr[q][k], c, acc[q]);     // detection.py:89
-      }
-#pragma unroll
-      for (int q = 0; q < PPL; ++q) {
-        const float s = yp_sigmoid(acc[q]);                                              // detection.py:90
-        v[q] = yp_clip(in[q] ? s : 0.0f, 0.0f, 1.0f);                                    // utils.py:133, L105
-      }
+      for (int k = 0; k < YP_MASK_DIM; ++k) acc = __builtin_fmaf(pr[k], cf[k], acc);     // detection.py:89
+      const float s = yp_sigmoid(acc);                                                  // detection.py:90
+      v = yp_clip(in ? s : 0.0f, 0.0f, 1.0f);                                           // utils.py:133, L105
     }
     if (live) {
-      const size_t o = (size_t)n * p.P + pix0;
-      if (PPL == 1) out_img[o] = v[0];
-      else {
-        vec_t w;
-        float* wf = reinterpret_cast<float*>(&w);
-#pragma unroll
-        for (int q = 0; q < PPL; ++q) wf[q] = v[q];
-        *reinterpret_cast<vec_t*>(out_img + o) = w;
-      }
-      if (bit_img) {
-#pragma unroll
-        for (int q = 0; q < PPL; ++q) bit_img[o + q] = v[q] > p.mask_threshold ? 1 : 0;   // train.py:497
-      }
+      const size_t o = (size_t)n * p.P + pix;
+      if (NT_STORE) __builtin_nontemporal_store(v, out_img + o); else out_img[o] = v;
+      if (bit_img) bit_img[o] = v > p.mask_threshold ? 1 : 0;                           // train.py:497
     }
   }
   if (p.zero_pad && live) {   // tf.zeros rows of detection.py:68
     for (int n = N; n < p.max_dets; ++n) {
-      const size_t o = (size_t)n * p.P + pix0;
-#pragma unroll
-      for (int q = 0; q < PPL; ++q) {
-        out_img[o + q] = 0.0f;
-        if (bit_img) bit_img[o + q] = 0;
-      }
+      const size_t o = (size_t)n * p.P + pix;
+      out_img[o] = 0.0f;
+      if (bit_img) bit_img[o] = 0;
     }
   }
 }
@@ -139,17 +123,12 @@ hipError_t yp_launch_mask_assemble(const yp_handle* h, int batch, const float* p
   a.P = h->cfg.proto_h * h->cfg.proto_w; a.pw = h->cfg.proto_w;
   a.max_dets = h->cfg.max_dets; a.sel_rows = h->sel_rows; a.zero_pad = h->cfg.zero_pad_masks;
   a.mask_threshold = h->cfg.mask_threshold;
-  const bool al16 = (((uintptr_t)det_masks) & 15u) == 0;
-  const int want = getenv("YP_MASK_PPL") ? atoi(getenv("YP_MASK_PPL")) : 1;
-  if (want == 4 && a.P % 4 == 0 && al16) {
-    const dim3 grid((a.P / 4 + 255) / 256, batch);
-    hipLaunchKernelGGL(mask_assemble_kernel<4>, grid, dim3(256), 0, st, a);
-  } else if (want >= 2 && a.P % 2 == 0 && al16) {
-    const dim3 grid((a.P / 2 + 255) / 256, batch);
-    hipLaunchKernelGGL(mask_assemble_kernel<2>, grid, dim3(256), 0, st, a);
-  } else {
-    const dim3 grid((a.P + 255) / 256, batch);
-    hipLaunchKernelGGL(mask_assemble_kernel<1>, grid, dim3(256), 0, st, a);
-  }
+  // Default-policy stores: the masks of the previous call usually still sit (dirty) in the
+  // Infinity Cache, and a caller that reuses its output buffer overwrites them there.
+  const bool nt = getenv("YP_MASK_NT") ? atoi(getenv("YP_MASK_NT")) != 0 : false;
+  const int bpi = (a.P + YP_MASK_BLOCK - 1) / YP_MASK_BLOCK;
+  const dim3 grid(8 * ((batch + 7) / 8) * bpi);
+  if (nt) hipLaunchKernelGGL((mask_assemble_kernel<true>), grid, dim3(YP_MASK_BLOCK), 0, st, a, bpi, batch);
+  else hipLaunchKernelGGL((mask_assemble_kernel<false>), grid, dim3(YP_MASK_BLOCK), 0, st, a, bpi, batch);
   return hipGetLastError();
 }

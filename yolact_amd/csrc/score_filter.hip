@@ -18,11 +18,15 @@ struct ScoreFilterArgs {
   int32_t* cand_count;   // per-class: [B,nseg] list lengths (atomic append)
   int32_t* tile_count;   // [B,ntiles] survivors of every tile (plain store; doubles as the slot count)
   int A, C, stride, nseg, ntiles, batch;
-  int bufb;              // bytes of one LDS tile buffer (>= ndma KiB and >= TA*stride*4)
-  int ndma;              // LDS-DMA wave-instructions per tile: ceil(TA*C*4 / 1024)
+  int bufb;              // bytes of one LDS tile buffer (TA*stride*4 rounded up to 16)
+  int nbuf;              // LDS tile buffers per wave: 2 or 3 (tiles in flight ahead of the current one: nbuf-1)
+  int ndma;              // full 1 KiB LDS-DMA wave-instructions per tile: floor(TA*C*4 / 1024)
+  int rem_lanes;         // lanes of the last, partial LDS-DMA instruction: (TA*C*4 % 1024) / 16
   int fast;              // 1: stride == C and every tile starts 16-byte aligned -> LDS-DMA path
 #ifdef YP_SF_STAMPS
   unsigned long long* dbg;   // diagnostic build only: per-wave phase cycle sums
+  int abl;                   // diagnostic build only: 1 = DMA only (no survivors), 2 = DMA + phase 1 only
+  int stagger;               // diagnostic build only: random start delay in [0, stagger) x 64 cycles
 #endif
   float conf, conf_lo;
   float pre_thresh;      // ln(1/conf - 1) + 1e-3: x_bg - x_fgmax must be below it to have p_fgmax > conf
@@ -87,17 +91,18 @@ typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void glb_void;
 
 // s_waitcnt vmcnt(n) with a run-time (wave-uniform) n: "wait until at most n vector-memory
-// operations of this wave are outstanding".  Counts above 6 fall back to a full drain.
+// operations of this wave are outstanding".  Any smaller count is a stricter, still correct wait;
+// counts above 31 are clamped to 31.
 __device__ __forceinline__ void wait_vmcnt_le(int n) {
-  switch (n) {
-    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
-    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
-    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
-    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+#define YP_VMC(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
+  switch (n < 31 ? n : 31) {
+    YP_VMC(1) YP_VMC(2) YP_VMC(3) YP_VMC(4) YP_VMC(5) YP_VMC(6) YP_VMC(7) YP_VMC(8) YP_VMC(9) YP_VMC(10)
+    YP_VMC(11) YP_VMC(12) YP_VMC(13) YP_VMC(14) YP_VMC(15) YP_VMC(16) YP_VMC(17) YP_VMC(18) YP_VMC(19) YP_VMC(20)
+    YP_VMC(21) YP_VMC(22) YP_VMC(23) YP_VMC(24) YP_VMC(25) YP_VMC(26) YP_VMC(27) YP_VMC(28) YP_VMC(29) YP_VMC(30)
+    YP_VMC(31)
     default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
   }
+#undef YP_VMC
 }
 
 // One PERSISTENT wave walks tiles of TA consecutive anchors (TA = 16, 32 or 64): tile blockIdx.x,
@@ -124,7 +129,11 @@ __global__ __launch_bounds__(YP_WAVE) void score_filter_kernel(const ScoreFilter
   extern __shared__ __align__(16) char lds_raw[];
   const int lane = threadIdx.x;
   const int C = p.C;
-  int2* s_list = reinterpret_cast<int2*>(lds_raw + 2 * p.bufb);  // (tile-local anchor, row max) of anchors past phase 1
+#ifdef YP_SF_STAMPS
+  const int ablm = p.abl % 100;          // diagnostic build: ablation mode; +100 = write no outputs at all
+  const bool nostore = p.abl >= 100;
+#endif
+  int2* s_list = reinterpret_cast<int2*>(lds_raw + p.nbuf * p.bufb);  // (tile-local anchor, row max) of anchors past phase 1
   u64* s_key = reinterpret_cast<u64*>(s_list + YP_WAVE);          // keys waiting to be written out
   const int grp = lane >> 4, j = lane & 15;
   int cidx[CPL];     // this lane's classes j, j+16, ... (clamped) and whether they exist
@@ -142,46 +151,55 @@ __global__ __launch_bounds__(YP_WAVE) void score_filter_kernel(const ScoreFilter
   const long long tile_bytes = (long long)TA * C * 4;
   const long long all_bytes = (long long)p.batch * img_bytes;
 
-  // LDS-DMA of one whole tile: exactly p.ndma wave-instructions, every lane active (bytes past the
-  // tile's end land in the buffer's padding).  Inline asm, so that the compiler's own s_waitcnt
-  // bookkeeping does not drain the prefetch of the NEXT tile before every LDS read of the current
-  // one (it cannot tell the two buffers apart); the DMA is waited for by hand with the counted wait
-  // at the top of the tile loop.  Scalar base + lane*16 + immediate; the immediate offset applies
-  // to the LDS address as well, so four 1 KiB pieces share one M0.
+  // LDS-DMA of one whole tile: p.ndma full-wave instructions of 1 KiB plus one partial instruction
+  // (p.rem_lanes lanes) - exactly the tile's bytes, so the buffers need no padding.  Inline asm, so
+  // that the compiler's own s_waitcnt bookkeeping does not drain the prefetch of the NEXT tiles
+  // before every LDS read of the current one (it cannot tell the buffers apart); the DMA is waited
+  // for by hand with the counted wait at the top of the tile loop.  Scalar base + lane*16 +
+  // immediate; the immediate offset applies to the LDS address as well, so four 1 KiB pieces share
+  // one M0.
   auto issue_dma = [&](int bb, int tt, uint32_t buf_off) {
     const long long off = bb * img_bytes + tt * tile_bytes;
     const char* gbase = reinterpret_cast<const char*>(p.cls) + off;
     uint32_t dst = lds_base + buf_off;
     int left = p.ndma;
-    if (off + (long long)left * 1024 > all_bytes) {
-      // only the last tile of the buffer: never read past the caller's allocation (clamped lanes)
+    if (off + tile_bytes > all_bytes) {
+      // only the last tile of the batch: never read past the caller's allocation (clamped lanes)
       const char* const last = reinterpret_cast<const char*>(p.cls) + all_bytes - 16;
-      for (; left > 0; --left, gbase += 1024, dst += 1024) {
+      for (; left >= 0; --left, gbase += 1024, dst += 1024) {
         const char* g = gbase + lane16;
         g = g < last ? g : last;
-        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(dst) : "memory");
+        if (left > 0 || lane < p.rem_lanes)
+          asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off nt" ::"v"(g), "s"(dst) : "memory");
       }
       return;
     }
     for (; left >= 4; left -= 4, gbase += 4096, dst += 4096)
       asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\t"
-                   "global_load_lds_dwordx4 %0, %1\n\t"
-                   "global_load_lds_dwordx4 %0, %1 offset:1024\n\t"
-                   "global_load_lds_dwordx4 %0, %1 offset:2048\n\t"
-                   "global_load_lds_dwordx4 %0, %1 offset:3072" ::"v"(lane16), "s"(gbase), "s"(dst) : "memory");
+                   "global_load_lds_dwordx4 %0, %1 nt\n\t"
+                   "global_load_lds_dwordx4 %0, %1 offset:1024 nt\n\t"
+                   "global_load_lds_dwordx4 %0, %1 offset:2048 nt\n\t"
+                   "global_load_lds_dwordx4 %0, %1 offset:3072 nt" ::"v"(lane16), "s"(gbase), "s"(dst) : "memory");
     if (left == 3)
       asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\t"
-                   "global_load_lds_dwordx4 %0, %1\n\t"
-                   "global_load_lds_dwordx4 %0, %1 offset:1024\n\t"
-                   "global_load_lds_dwordx4 %0, %1 offset:2048" ::"v"(lane16), "s"(gbase), "s"(dst) : "memory");
+                   "global_load_lds_dwordx4 %0, %1 nt\n\t"
+                   "global_load_lds_dwordx4 %0, %1 offset:1024 nt\n\t"
+                   "global_load_lds_dwordx4 %0, %1 offset:2048 nt" ::"v"(lane16), "s"(gbase), "s"(dst) : "memory");
     else if (left == 2)
       asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\t"
-                   "global_load_lds_dwordx4 %0, %1\n\t"
-                   "global_load_lds_dwordx4 %0, %1 offset:1024" ::"v"(lane16), "s"(gbase), "s"(dst) : "memory");
+                   "global_load_lds_dwordx4 %0, %1 nt\n\t"
+                   "global_load_lds_dwordx4 %0, %1 offset:1024 nt" ::"v"(lane16), "s"(gbase), "s"(dst) : "memory");
     else if (left == 1)
       asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\t"
-                   "global_load_lds_dwordx4 %0, %1" ::"v"(lane16), "s"(gbase), "s"(dst) : "memory");
+                   "global_load_lds_dwordx4 %0, %1 nt" ::"v"(lane16), "s"(gbase), "s"(dst) : "memory");
+    if (lane < p.rem_lanes) {
+      gbase += left * 1024;
+      dst += left * 1024;
+      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                   "global_load_lds_dwordx4 %0, %1 nt" ::"v"(lane16), "s"(gbase), "s"(dst) : "memory");
+    }
   };
+  const int nvm = p.ndma + (p.rem_lanes > 0 ? 1 : 0);   // vector-memory instructions per tile DMA
 
   int flat = blockIdx.x;
   if (flat >= total_tiles) return;
@@ -192,35 +210,62 @@ __global__ __launch_bounds__(YP_WAVE) void score_filter_kernel(const ScoreFilter
     tt += G;
     while (tt >= p.ntiles) { tt -= p.ntiles; ++bb; }
   };
-  if (p.fast) issue_dma(b, tix, 0u);
   advance(nb, ntix);
-  int nst = 0;    // store instructions issued since the last DMA issue (wave-uniform)
+  // Prefetch queue: the DMAs of the current tile and of the next nbuf-2 tiles are in flight.
+  // y1 / y2 = vector-memory instructions issued after the oldest / second pending DMA: the counted
+  // wait for the oldest one leaves exactly those in flight.
+  int pf_flat = flat, pb = b, ptix = tix, pbuf = 0, cbuf = 0;
+  int npend = 0, y1 = 0, y2 = 0;
+  auto note_vmem = [&](int k) { y1 += npend >= 1 ? k : 0; y2 += npend >= 2 ? k : 0; };
+  auto prefetch = [&]() {
+    if (pf_flat >= total_tiles) return;
+    issue_dma(pb, ptix, (uint32_t)(pbuf * p.bufb));
+    note_vmem(nvm);
+    ++npend;
+    pf_flat += G;
+    advance(pb, ptix);
+    pbuf = pbuf + 1 == p.nbuf ? 0 : pbuf + 1;
+  };
+  if (p.fast) for (int d = 1; d < p.nbuf; ++d) prefetch();
   int pend_flat = -1, pend_nk = 0;   // cross-class mode: tile whose outputs are still to be stored
 #ifdef YP_SF_STAMPS
   long long dd[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const long long Tstart = clock64();
 #define STAMP(v) const long long v = clock64()
 #else
 #define STAMP(v)
 #endif
-  int par = 0;
-  for (; flat < total_tiles; flat += G, par ^= 1, b = nb, tix = ntix, advance(nb, ntix)) {
+  for (; flat < total_tiles; flat += G, cbuf = (cbuf + 1 == p.nbuf ? 0 : cbuf + 1), b = nb, tix = ntix, advance(nb, ntix)) {
     const int a0 = tix * TA;
     const int na = min(TA, p.A - a0);
-    float* tile = reinterpret_cast<float*>(lds_raw + (par ? p.bufb : 0));
+    float* tile = reinterpret_cast<float*>(lds_raw + cbuf * p.bufb);
 
     // ---- phase 0 ------------------------------------------------------------------------------
     STAMP(T0);
     if (p.fast) {
-      wait_vmcnt_le(nst);                      // this tile's DMA has landed; younger stores stay in flight
+      wait_vmcnt_le(y1);                       // this tile's DMA has landed; everything younger stays in flight
+      y1 = y2; y2 = 0; --npend;
 #ifdef YP_SF_STAMPS
       dd[1] += clock64() - T0;
 #endif
-      if (flat + G < total_tiles) issue_dma(nb, ntix, par ? 0u : (uint32_t)p.bufb);
-      nst = 0;
+#ifdef YP_SF_STAMPS
+      const long long Ti0 = clock64();
+#endif
+      prefetch();                              // into the buffer the previous tile has just left
+#ifdef YP_SF_STAMPS
+      dd[4] += clock64() - Ti0;
+#endif
+#ifdef YP_SF_STAMPS
+      if (nostore) pend_flat = -1;
+#endif
       if (MODE == YP_NMS_CROSS_CLASS && pend_flat >= 0) {   // previous tile's outputs (s_key is rewritten only in phase 2)
         if (lane == 0) p.tile_count[pend_flat] = pend_nk;
+#ifdef YP_SF_STAMPS
+        if (lane < (ablm == 19 ? 1 : max(pend_nk, 1))) p.cand[(size_t)pend_flat * TA + lane] = s_key[lane];
+#else
         if (lane < max(pend_nk, 1)) p.cand[(size_t)pend_flat * TA + lane] = s_key[lane];
-        nst = 2;
+#endif
+        note_vmem(2);
       }
     } else {
       const int nelem = na * C;
@@ -235,8 +280,11 @@ __global__ __launch_bounds__(YP_WAVE) void score_filter_kernel(const ScoreFilter
     STAMP(T2);
     // ---- phase 1: LPA lanes per anchor --------------------------------------------------------
     const int al1 = lane / LPA, q = lane % LPA;
-    float m;
-    bool pre;
+    float m = 0.0f;
+    bool pre = false;
+#ifdef YP_SF_STAMPS
+    if (ablm != 1)
+#endif
     {
       const float* row = tile + min(al1, na - 1) * p.stride;
       const float x0 = row[0];
@@ -263,6 +311,41 @@ __global__ __launch_bounds__(YP_WAVE) void score_filter_kernel(const ScoreFilter
       m = fmaxf(x0, xf);
       pre = (al1 < na) && (q == 0) && ((x0 - xf) < p.pre_thresh);
     }
+#ifdef YP_SF_STAMPS
+    if (ablm >= 2 && (ablm < 12 || ablm == 15 || ablm == 16)) pre = false;
+    if (ablm == 15 || ablm == 16) {   // dense VALU (8 independent FMA chains), random (15) or fixed (16) amount per tile
+      float a0_ = m, a1_ = m + 1.f, a2_ = m + 2.f, a3_ = m + 3.f, a4_ = m + 4.f, a5_ = m + 5.f, a6_ = m + 6.f, a7_ = m + 7.f;
+      const int nblk = ablm == 16 ? 10 : (int)((((uint32_t)flat * 0x9E3779B1u) >> 20) % 21u);
+      for (int bq = 0; bq < nblk; ++bq) {
+#pragma unroll
+        for (int i = 0; i < 10; ++i) {
+          a0_ = __builtin_fmaf(a0_, 1.0001f, 0.5f); a1_ = __builtin_fmaf(a1_, 1.0001f, 0.5f);
+          a2_ = __builtin_fmaf(a2_, 1.0001f, 0.5f); a3_ = __builtin_fmaf(a3_, 1.0001f, 0.5f);
+          a4_ = __builtin_fmaf(a4_, 1.0001f, 0.5f); a5_ = __builtin_fmaf(a5_, 1.0001f, 0.5f);
+          a6_ = __builtin_fmaf(a6_, 1.0001f, 0.5f); a7_ = __builtin_fmaf(a7_, 1.0001f, 0.5f);
+        }
+      }
+      if (a0_ + a1_ + a2_ + a3_ + a4_ + a5_ + a6_ + a7_ == 123.456f) s_list[lane] = make_int2(0, 0);
+    }
+    if (ablm == 11) {   // random amount of dependent FMA work per tile (mean 750): desynchronises the waves
+      float acc = m;
+      const int nf = (int)((((uint32_t)flat * 0x9E3779B1u) >> 20) % 1501u);
+      for (int i = 0; i < nf; ++i) acc = __builtin_fmaf(acc, 1.0001f, 0.5f);
+      if (acc == 123.456f) s_list[lane] = make_int2(0, 0);
+    }
+    if (ablm >= 6 && ablm <= 9) {   // phase 2 replaced by ~3k cycles of one instruction kind
+      float acc = m;
+      if (ablm == 6) { for (int i = 0; i < 750; ++i) acc = __builtin_fmaf(acc, 1.0001f, 0.5f); }
+      if (ablm == 7) { for (int i = 0; i < 375; ++i) acc = acc + dpp_f<YP_DPP_ROR(1)>(acc); }
+      if (ablm == 8) { for (int i = 0; i < 190; ++i) acc = __builtin_amdgcn_rcpf(acc) + 1.0f; }
+      if (ablm == 9) { for (int i = 0; i < 300; ++i) acc = acc + (__ballot(acc > (float)i) ? 1.0f : 2.0f); }
+      if (acc == 123.456f) s_list[lane] = make_int2(0, 0);
+    }
+    if (ablm == 4 || ablm == 5) {   // phase 2 replaced by an idle delay: fixed, or random per tile
+      const int nd = ablm == 4 ? 6 : (int)((((uint32_t)flat * 0x9E3779B1u) >> 20) % 13u);
+      for (int i = 0; i < nd; ++i) __builtin_amdgcn_s_sleep(8);
+    }
+#endif
     const u64 pm = __ballot(pre);
     const int npass = __popcll(pm);
     if (pre) s_list[__popcll(pm & lt_mask)] = make_int2(al1, __float_as_int(m));   // (tile-local anchor, row max)
@@ -285,6 +368,19 @@ __global__ __launch_bounds__(YP_WAVE) void score_filter_kernel(const ScoreFilter
       float e[CPL];
 #pragma unroll
       for (int i = 0; i < CPL; ++i) e[i] = r[cidx[i]];
+#ifdef YP_SF_STAMPS
+      if (ablm == 13) {   // no LDS reads of the tile in phase 2: synthetic logits
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) e[i] = ma - 0.37f * (float)(cidx[i] + al);
+      }
+      if (ablm == 14) {   // LDS reads only, no arithmetic
+        float sacc = 0.0f;
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) sacc += e[i];
+        if (sacc == 123.456f) s_key[lane] = 1;
+        continue;
+      }
+#endif
 #pragma unroll
       for (int i = 0; i < CPL; ++i) e[i] = yp_exp_le0(e[i] - ma) * okf[i];   // x <= row max; 0 for c >= C
       float s = e[0];                                                        // s_j = e_j + e_{j+16} + ...
@@ -293,10 +389,16 @@ __global__ __launch_bounds__(YP_WAVE) void score_filter_kernel(const ScoreFilter
       float em = j > 0 ? e[0] : 0.0f;                        // class 0 is background (detection.py:59)
 #pragma unroll
       for (int i = 1; i < CPL; ++i) em = max_nonneg(em, e[i]);   // e >= 0: integer max on the bit patterns
+#ifdef YP_SF_STAMPS
+      if (ablm == 17) { if (s + em == 123.456f) s_key[lane] = 1; continue; }   // exponentials only
+#endif
       const float S = grp16_sum(s);
       em = grp16_max_nonneg(em);
       // IEEE division is monotone, so max_c fl(e_c/S) = fl(max_c e_c / S)              (detection.py:62)
       const float pmax = em / S;
+#ifdef YP_SF_STAMPS
+      if (ablm == 18) { if (pmax == 123.456f) s_key[lane] = 1; continue; }    // + DPP reductions + division
+#endif
       const bool surv = act && (pmax > p.conf);                                      // detection.py:73
       const bool lead = surv && j == 0;
       const u64 bl = __ballot(lead);
@@ -314,6 +416,9 @@ __global__ __launch_bounds__(YP_WAVE) void score_filter_kernel(const ScoreFilter
         }
         cnt = grp16_sum_i(cnt);
         int arg = grp16_min(cmin);
+#ifdef YP_SF_STAMPS
+        if (ablm == 20) { cnt = 1; arg = 1; }
+#endif
         if (__ballot(surv && cnt > 1)) {   // rare: several classes within 2^-21 -> exact test
           int a2 = 0x7fffffff;
 #pragma unroll
@@ -368,7 +473,7 @@ __global__ __launch_bounds__(YP_WAVE) void score_filter_kernel(const ScoreFilter
                     p.cand[seg * p.A + qpos] = key;
                   }
                 }
-                nst = 100;   // unknown mix of atomics and stores in flight: next wait drains everything
+                y1 = y2 = -1000;   // unknown mix of atomics and stores in flight: the next waits drain everything
                 __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): s_key is rewritten below
                 ncand = 0;
               }
@@ -388,7 +493,7 @@ __global__ __launch_bounds__(YP_WAVE) void score_filter_kernel(const ScoreFilter
               p.cand[seg * p.A + qpos] = key;
             }
           }
-          nst = 100;
+          y1 = y2 = -1000;
           __builtin_amdgcn_s_waitcnt(0xC07F);
           ncand = 0;
         }
@@ -406,11 +511,11 @@ __global__ __launch_bounds__(YP_WAVE) void score_filter_kernel(const ScoreFilter
       pend_nk = nk;
     } else {
       if (lane == 0) p.tile_count[flat] = nk;
-      nst += 1;
+      note_vmem(1);
       if (MODE == YP_NMS_CROSS_CLASS) {
-        // always issued (lane 0 writes an ignored slot when nk == 0) so that `nst` is exact
+        // always issued (lane 0 writes an ignored slot when nk == 0) so that the count is exact
         if (lane < max(nk, 1)) p.cand[(size_t)flat * TA + lane] = s_key[lane];
-        nst += 1;
+        note_vmem(1);
       } else {
         for (int l0 = 0; l0 < ncand; l0 += YP_WAVE) {
           const int l = l0 + lane;
@@ -421,10 +526,12 @@ __global__ __launch_bounds__(YP_WAVE) void score_filter_kernel(const ScoreFilter
             p.cand[seg * p.A + qpos] = key;
           }
         }
-        // the returning atomics above forced a full drain before their stores; only those stores
-        // (one instruction per started batch of 64) and nothing older can still be in flight,
-        // unless there was no candidate at all
-        nst = ncand > 0 ? (ncand + YP_WAVE - 1) / YP_WAVE : nst;
+        // the returning atomics above forced a full drain before their stores: every pending DMA has
+        // landed, and only those stores (one instruction per started batch of 64) can be in flight
+        if (ncand > 0) {
+          y1 = y2 = 0;
+          note_vmem((ncand + YP_WAVE - 1) / YP_WAVE);
+        }
       }
     }
     // LDS reads of this tile must have returned before the DMA issued at the top of the next
@@ -433,14 +540,18 @@ __global__ __launch_bounds__(YP_WAVE) void score_filter_kernel(const ScoreFilter
     __builtin_amdgcn_wave_barrier();
 #ifdef YP_SF_STAMPS
     { const long long T5 = clock64(); long long T1x = T0; if (p.fast) T1x = T2; (void)T1x;
-      dd[0] += T2 - T0; dd[2] += T3 - T2; dd[3] += T4 - T3; dd[4] += T5 - T4; dd[5] += 1; dd[6] += npass; }
+      dd[0] += T2 - T0; dd[2] += T3 - T2; dd[3] += T4 - T3; (void)T5; dd[5] += 1; dd[6] += npass; }
 #endif
   }   // tile loop
+#ifdef YP_SF_STAMPS
+  if (nostore) pend_flat = -1;
+#endif
   if (MODE == YP_NMS_CROSS_CLASS && pend_flat >= 0) {
     if (lane == 0) p.tile_count[pend_flat] = pend_nk;
     if (lane < pend_nk) p.cand[(size_t)pend_flat * TA + lane] = s_key[lane];
   }
 #ifdef YP_SF_STAMPS
+  dd[7] = clock64() - Tstart;
   if (p.dbg && lane == 0) { unsigned long long* o = p.dbg + (size_t)blockIdx.x * 8; for (int i = 0; i < 8; ++i) o[i] = dd[i]; }
 #endif
 }
@@ -466,21 +577,24 @@ hipError_t yp_launch_score_filter(const yp_handle* h, int batch, const float* pr
   a.pre_thresh = h->pre_thresh;
   const int TA = h->tile_anchors;
   a.ntiles = h->ntiles; a.batch = batch;
-  a.ndma = h->sf_ndma; a.bufb = h->sf_bufb;
+  a.ndma = h->sf_ndma; a.rem_lanes = h->sf_rem; a.bufb = h->sf_bufb; a.nbuf = h->sf_nbuf;
 #ifdef YP_SF_STAMPS
   a.dbg = (unsigned long long*)h->dbg;
+  a.abl = getenv("YP_SF_ABL") ? atoi(getenv("YP_SF_ABL")) : 0;
+  a.stagger = getenv("YP_SF_STAGGER") ? atoi(getenv("YP_SF_STAGGER")) : 0;
 #endif
   const bool fast_ok = (a.stride == a.C) && (((long long)a.A * a.C) % 4 == 0) && ((((uintptr_t)pred_cls) & 15u) == 0) &&
                        ((long long)batch * a.A * a.C / 4 < 0x7fffffffLL);
   a.fast = fast_ok ? 1 : 0;
-  const size_t lds = 2 * (size_t)a.bufb + YP_WAVE * sizeof(int2) + 128 * sizeof(u64);
+  const size_t lds = (size_t)a.nbuf * a.bufb + YP_WAVE * sizeof(int2) + 128 * sizeof(u64);
   int cpl = (a.C + 15) / 16;                       // classes per lane in phase 2
   if (cpl == 7) cpl = 8; else if (cpl > 8 && cpl <= 12) cpl = 12; else if (cpl > 12) cpl = 16;
   // persistent grid: as many single-wave workgroups as the LDS lets the chip hold
   const int total_tiles = batch * h->ntiles;
-  // (measured on MI355X: single-wave workgroups become co-resident up to ~128-140 KiB of LDS per CU,
-  //  one or two fewer than the occupancy API reports; an over-subscribed persistent grid runs in two rounds)
-  int per_cu = (int)((128 * 1024) / lds);
+  // (measured on MI355X with a residency census: LDS is handed out in units of 1280 bytes, 128 units
+  //  per CU - the occupancy API reports more than that for some sizes; an over-subscribed persistent
+  //  grid would run in two rounds)
+  int per_cu = (int)(128 / ((lds + 1279) / 1280));
   per_cu = per_cu < 1 ? 1 : (per_cu > 16 ? 16 : per_cu);
   const int wpc = getenv("YP_SF_WAVES_PER_CU") ? atoi(getenv("YP_SF_WAVES_PER_CU")) : per_cu;
   const int nblocks = total_tiles < h->num_cus * wpc ? total_tiles : h->num_cus * wpc;
