@@ -77,35 +77,64 @@ __global__ __launch_bounds__(YP_MASK_BLOCK) void mask_assemble_kernel(const Mask
   const float frow = live ? (float)r : -1.0f;                  // tf.range(..., dtype=float32), utils/utils.py:119-120
   const float fcol = live ? (float)(pix - r * p.pw) : -1.0f;
 
-  float* const out_img = p.masks + (size_t)b * p.max_dets * p.P;
-  uint8_t* const bit_img = p.bitmaps ? p.bitmaps + (size_t)b * p.max_dets * p.P : nullptr;
-
-  // Crop edges and coefficients of detection n are wave-uniform and were written by the previous
-  // kernel: read them through the constant address space so they arrive by scalar loads (SGPRs,
-  // scalar cache) and never wait on this wave's own outstanding vector stores.
+  float* optr = p.masks + ((size_t)b * p.max_dets) * p.P + pix;
+  uint8_t* bptr = p.bitmaps ? p.bitmaps + ((size_t)b * p.max_dets) * p.P + pix : nullptr;
   typedef const __attribute__((address_space(4))) float cfloat;
   cfloat* const crop_c = (cfloat*)(p.crop + (size_t)b * p.sel_rows);
   cfloat* const coef_c = (cfloat*)(p.coef + (size_t)b * p.sel_rows * YP_MASK_DIM);
-  for (int n = 0; n < N; ++n) {
-    float4 cb;
-    cb.x = crop_c[4 * n + 0]; cb.y = crop_c[4 * n + 1]; cb.z = crop_c[4 * n + 2]; cb.w = crop_c[4 * n + 3];
-    cfloat* const cf = coef_c + n * YP_MASK_DIM;
-    // mask_left & mask_right & mask_bottom & mask_top, float compares (utils/utils.py:125-130)
-    const bool in = live && (fcol >= cb.x) && (fcol < cb.y) && (frow >= cb.z) && (frow < cb.w);
-    float v = 0.0f;
-    if (__ballot(in)) {
-      float acc = 0.0f;
+
+  // Which detections can touch this wave's 64 pixels at all?  Lane l tests detection g*64+l against
+  // a bounding range of the wave's pixels (a superset test: the per-pixel compares below decide the
+  // values); the ballots give a bit per detection.  Rows of all other detections are plain zeros
+  // and cost a handful of instructions each - the kernel is otherwise bound by instruction issue,
+  // not by HBM.
+  const int lane = t & 63;
+  const int w0 = base_pix + (t & ~63), w1 = min(w0 + 63, p.P - 1);
+  u64 rel[YP_SORT_MAX / 64] = {0ull, 0ull, 0ull, 0ull};
+  if (w0 < p.P) {
+    const int r0 = w0 / p.pw, r1 = w1 / p.pw;
+    int c0 = w0 - r0 * p.pw, c1 = w1 - r1 * p.pw;
+    if (r1 > r0) { c0 = 0; c1 = p.pw - 1; }
+    const float fr0 = (float)r0, fr1 = (float)r1, fc0 = (float)c0, fc1 = (float)c1;
 #pragma unroll
-      for (int k = 0; k < YP_MASK_DIM; ++k) acc = __builtin_fmaf(pr[k], cf[k], acc);     // detection.py:89
-      const float s = yp_sigmoid(acc);                                                  // detection.py:90
-      v = yp_clip(in ? s : 0.0f, 0.0f, 1.0f);                                           // utils.py:133, L105
-    }
-    if (live) {
-      const size_t o = (size_t)n * p.P + pix;
-      if (NT_STORE) __builtin_nontemporal_store(v, out_img + o); else out_img[o] = v;
-      if (bit_img) bit_img[o] = v > p.mask_threshold ? 1 : 0;                           // train.py:497
+    for (int g = 0; g < YP_SORT_MAX / 64; ++g) {
+      if (g * 64 < N) {
+        const int n = g * 64 + lane;
+        const float4 cb = p.crop[(size_t)b * p.sel_rows + min(n, N - 1)];
+        const bool hit = (n < N) && (fc1 >= cb.x) && (fc0 < cb.y) && (fr1 >= cb.z) && (fr0 < cb.w);
+        rel[g] = __ballot(hit);
+      }
     }
   }
+
+  for (int n = 0; n < N; ++n, optr += p.P, bptr += (bptr ? p.P : 0)) {
+    const int g = n >> 6;
+    const u64 word = g == 0 ? rel[0] : (g == 1 ? rel[1] : (g == 2 ? rel[2] : rel[3]));
+    float v = 0.0f;
+    if ((word >> (n & 63)) & 1ull) {   // wave-uniform
+      // Crop edges and coefficients of detection n are wave-uniform and were written by the previous
+      // kernel: read them through the constant address space so they arrive by scalar loads (SGPRs,
+      // scalar cache) and never wait on this wave's own outstanding vector stores.
+      float4 cb;
+      cb.x = crop_c[4 * n + 0]; cb.y = crop_c[4 * n + 1]; cb.z = crop_c[4 * n + 2]; cb.w = crop_c[4 * n + 3];
+      cfloat* const cf = coef_c + n * YP_MASK_DIM;
+      // mask_left & mask_right & mask_bottom & mask_top, float compares (utils/utils.py:125-130)
+      const bool in = live && (fcol >= cb.x) && (fcol < cb.y) && (frow >= cb.z) && (frow < cb.w);
+      if (__ballot(in)) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int k = 0; k < YP_MASK_DIM; ++k) acc = __builtin_fmaf(pr[k], cf[k], acc);     // detection.py:89
+        const float sg = yp_sigmoid(acc);                                                  // detection.py:90
+        v = yp_clip(in ? sg : 0.0f, 0.0f, 1.0f);                                            // utils.py:133, L105
+      }
+    }
+    if (live) {
+      if (NT_STORE) __builtin_nontemporal_store(v, optr); else *optr = v;
+      if (bptr) *bptr = v > p.mask_threshold ? 1 : 0;                                      // train.py:497
+    }
+  }
+  float* const out_img = p.masks + (size_t)b * p.max_dets * p.P;
+  uint8_t* const bit_img = p.bitmaps ? p.bitmaps + (size_t)b * p.max_dets * p.P : nullptr;
   if (p.zero_pad && live) {   // tf.zeros rows of detection.py:68
     for (int n = N; n < p.max_dets; ++n) {
       const size_t o = (size_t)n * p.P + pix;
