@@ -82,6 +82,9 @@ extern "C" int yp_create(const yp_config* cfg, yp_handle** out) {
     const int v = atoi(ev);
     if (v == 2 || v == 3) h->sf_nbuf = v;
   }
+  h->sf_stg = 0;
+  if (const char* ev = getenv("YP_SF_STG")) h->sf_stg = atoi(ev) != 0;   // tile in flight held in VGPRs: one LDS buffer
+  if (h->sf_stg) { h->tile_anchors = 32; h->sf_nbuf = 1; }
   for (;;) {   // the LDS tile buffers of a wave must fit the 64 KiB a workgroup may take without opt-in
     const int row_bytes = h->tile_anchors * h->lds_stride * (int)sizeof(float);
     const int dma_bytes = h->tile_anchors * c.num_classes * (int)sizeof(float);   // multiple of 64
@@ -91,7 +94,7 @@ extern "C" int yp_create(const yp_config* cfg, yp_handle** out) {
     if (h->sf_nbuf * h->sf_bufb + 2048 <= 64 * 1024 || h->tile_anchors == 16) break;
     h->tile_anchors /= 2;
   }
-  if (h->sf_nbuf * h->sf_bufb + 2048 > 64 * 1024) h->sf_nbuf = 2;
+  if (!h->sf_stg && h->sf_nbuf * h->sf_bufb + 2048 > 64 * 1024) h->sf_nbuf = 2;
 
   h->ntiles = (c.num_anchors + h->tile_anchors - 1) / h->tile_anchors;
   const size_t B = (size_t)c.max_batch, A = (size_t)c.num_anchors, nseg = (size_t)h->nseg;

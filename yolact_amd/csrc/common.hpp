@@ -131,6 +131,7 @@ struct yp_handle {
   int ntiles;           // ceil(A / TA)
   int num_cus;          // compute units of the device (256 on MI355X)
   int sf_ndma, sf_rem;  // score_filter: full 1 KiB LDS-DMA pieces per tile + lanes of the partial last piece
+  int sf_stg;           // score_filter: 1 = the tile in flight is staged in VGPRs (one LDS buffer per wave)
   int sf_bufb, sf_nbuf; // score_filter: bytes per LDS tile buffer, buffers per wave (prefetch distance + 1)
 #ifdef YP_SF_STAMPS
   void* dbg;            // diagnostic build only

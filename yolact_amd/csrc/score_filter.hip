@@ -122,9 +122,14 @@ __device__ __forceinline__ void wait_vmcnt_le(int n) {
 //            boxes are decoded later, for the few candidates that reach the NMS).  The stores are
 //            not waited for: the wait for tile i+1's DMA is a COUNTED vmcnt that leaves exactly the
 //            store instructions issued after that DMA in flight.
-template <int MODE, int CPL, int TA>
+template <int MODE, int CPL, int TA, bool STG>
 __global__ __launch_bounds__(YP_WAVE) void score_filter_kernel(const ScoreFilterArgs p) {
   constexpr int LPA = YP_WAVE / TA;   // lanes per anchor in phase 1
+  // STG: the tile in flight is held in VGPRs (NLD 16-byte loads per lane) instead of a second LDS
+  // buffer, so a wave needs one LDS tile only and twice as many waves fit a CU.
+  constexpr int NLD = STG ? (TA * CPL) / 16 : 1;
+  typedef float nat4 __attribute__((ext_vector_type(4)));
+  nat4 stg[NLD];
   constexpr int KCAP = 128;           // capacity of the key list
   extern __shared__ __align__(16) char lds_raw[];
   const int lane = threadIdx.x;
@@ -200,6 +205,17 @@ __global__ __launch_bounds__(YP_WAVE) void score_filter_kernel(const ScoreFilter
     }
   };
   const int nvm = p.ndma + (p.rem_lanes > 0 ? 1 : 0);   // vector-memory instructions per tile DMA
+  // STG: the tile's bytes as NLD non-temporal 16-byte loads per lane (addresses past the tile are
+  // clamped to its last 16 bytes; those registers land in LDS space nobody reads)
+  auto issue_loads = [&](int bb, int tt) {
+    const int nbytes = min(TA, p.A - tt * TA) * C * 4;
+    const char* g = reinterpret_cast<const char*>(p.cls) + (bb * img_bytes + tt * tile_bytes);
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) {
+      const int o = min(u * 1024 + (int)lane16, nbytes - 16);
+      stg[u] = __builtin_nontemporal_load(reinterpret_cast<const nat4*>(g + o));
+    }
+  };
 
   int flat = blockIdx.x;
   if (flat >= total_tiles) return;
@@ -226,7 +242,8 @@ __global__ __launch_bounds__(YP_WAVE) void score_filter_kernel(const ScoreFilter
     advance(pb, ptix);
     pbuf = pbuf + 1 == p.nbuf ? 0 : pbuf + 1;
   };
-  if (p.fast) for (int d = 1; d < p.nbuf; ++d) prefetch();
+  if (STG) { if (p.fast) issue_loads(b, tix); }
+  else if (p.fast) for (int d = 1; d < p.nbuf; ++d) prefetch();
   int pend_flat = -1, pend_nk = 0;   // cross-class mode: tile whose outputs are still to be stored
 #ifdef YP_SF_STAMPS
   long long dd[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -242,7 +259,15 @@ __global__ __launch_bounds__(YP_WAVE) void score_filter_kernel(const ScoreFilter
 
     // ---- phase 0 ------------------------------------------------------------------------------
     STAMP(T0);
-    if (p.fast) {
+    if (STG && p.fast) {
+      nat4* t4 = reinterpret_cast<nat4*>(tile);
+#pragma unroll
+      for (int u = 0; u < NLD; ++u)
+        if (u * 1024 + (int)lane16 < p.bufb) t4[u * YP_WAVE + lane] = stg[u];
+      if (flat + G < total_tiles) issue_loads(nb, ntix);      // in flight while this tile is processed
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+    } else if (p.fast) {
       wait_vmcnt_le(y1);                       // this tile's DMA has landed; everything younger stays in flight
       y1 = y2; y2 = 0; --npend;
 #ifdef YP_SF_STAMPS
@@ -504,7 +529,7 @@ __global__ __launch_bounds__(YP_WAVE) void score_filter_kernel(const ScoreFilter
     STAMP(T4);
     // ---- phase 3: survivors ---------------------------------------------------------------------
     __builtin_amdgcn_wave_barrier();
-    if (MODE == YP_NMS_CROSS_CLASS && p.fast) {
+    if (MODE == YP_NMS_CROSS_CLASS && p.fast && !STG) {
       // deferred: the two stores are issued right AFTER the next iteration's DMA issue, so that they
       // never sit in front of it in this wave's in-order vector-memory queue
       pend_flat = flat;
@@ -556,10 +581,10 @@ __global__ __launch_bounds__(YP_WAVE) void score_filter_kernel(const ScoreFilter
 #endif
 }
 
-template <int MODE, int TA>
+template <int MODE, int TA, bool STG>
 static void launch_mode(int cpl, int nblocks, size_t lds, hipStream_t st, const ScoreFilterArgs& a) {
   const dim3 grid(nblocks);
-#define YP_SF_CASE(N) case N: hipLaunchKernelGGL((score_filter_kernel<MODE, N, TA>), grid, dim3(YP_WAVE), lds, st, a); break;
+#define YP_SF_CASE(N) case N: hipLaunchKernelGGL((score_filter_kernel<MODE, N, TA, STG>), grid, dim3(YP_WAVE), lds, st, a); break;
   switch (cpl) {
     YP_SF_CASE(1) YP_SF_CASE(2) YP_SF_CASE(3) YP_SF_CASE(4) YP_SF_CASE(5) YP_SF_CASE(6)
     YP_SF_CASE(8) YP_SF_CASE(12) YP_SF_CASE(16)
@@ -599,8 +624,9 @@ hipError_t yp_launch_score_filter(const yp_handle* h, int batch, const float* pr
   const int wpc = getenv("YP_SF_WAVES_PER_CU") ? atoi(getenv("YP_SF_WAVES_PER_CU")) : per_cu;
   const int nblocks = total_tiles < h->num_cus * wpc ? total_tiles : h->num_cus * wpc;
   const bool cc = h->cfg.nms_mode == YP_NMS_CROSS_CLASS;
-  if (TA == 64) { if (cc) launch_mode<YP_NMS_CROSS_CLASS, 64>(cpl, nblocks, lds, st, a); else launch_mode<YP_NMS_PER_CLASS, 64>(cpl, nblocks, lds, st, a); }
-  else if (TA == 32) { if (cc) launch_mode<YP_NMS_CROSS_CLASS, 32>(cpl, nblocks, lds, st, a); else launch_mode<YP_NMS_PER_CLASS, 32>(cpl, nblocks, lds, st, a); }
-  else { if (cc) launch_mode<YP_NMS_CROSS_CLASS, 16>(cpl, nblocks, lds, st, a); else launch_mode<YP_NMS_PER_CLASS, 16>(cpl, nblocks, lds, st, a); }
+  if (h->sf_stg) { if (cc) launch_mode<YP_NMS_CROSS_CLASS, 32, true>(cpl, nblocks, lds, st, a); else launch_mode<YP_NMS_PER_CLASS, 32, true>(cpl, nblocks, lds, st, a); }
+  else if (TA == 64) { if (cc) launch_mode<YP_NMS_CROSS_CLASS, 64, false>(cpl, nblocks, lds, st, a); else launch_mode<YP_NMS_PER_CLASS, 64, false>(cpl, nblocks, lds, st, a); }
+  else if (TA == 32) { if (cc) launch_mode<YP_NMS_CROSS_CLASS, 32, false>(cpl, nblocks, lds, st, a); else launch_mode<YP_NMS_PER_CLASS, 32, false>(cpl, nblocks, lds, st, a); }
+  else { if (cc) launch_mode<YP_NMS_CROSS_CLASS, 16, false>(cpl, nblocks, lds, st, a); else launch_mode<YP_NMS_PER_CLASS, 16, false>(cpl, nblocks, lds, st, a); }
   return hipGetLastError();
 }
