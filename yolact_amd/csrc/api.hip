@@ -9,8 +9,6 @@
 #include <new>
 
 #include "common.hpp"
-#include <vector>
-#include <algorithm>
 
 static thread_local char g_err[512] = "";
 
@@ -72,42 +70,39 @@ extern "C" int yp_create(const yp_config* cfg, yp_handle** out) {
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c.device_id) != hipSuccess || cus < 1) cus = 256;
     h->num_cus = cus;
   }
-  h->tile_anchors = 32;
-  if (const char* ev = getenv("YP_TILE_ANCHORS")) {   // tuning knob for benchmarks
-    const int v = atoi(ev);
-    if (v == 16 || v == 32 || v == 64) h->tile_anchors = v;
-  }
-  h->sf_nbuf = 2;
-  if (const char* ev = getenv("YP_SF_NBUF")) {        // tuning knob for benchmarks
-    const int v = atoi(ev);
-    if (v == 2 || v == 3) h->sf_nbuf = v;
-  }
-  h->sf_stg = 0;
-  if (const char* ev = getenv("YP_SF_STG")) h->sf_stg = atoi(ev) != 0;   // tile in flight held in VGPRs: one LDS buffer
-  if (h->sf_stg) { h->tile_anchors = 32; h->sf_nbuf = 1; }
-  for (;;) {   // the LDS tile buffers of a wave must fit the 64 KiB a workgroup may take without opt-in
-    const int row_bytes = h->tile_anchors * h->lds_stride * (int)sizeof(float);
-    const int dma_bytes = h->tile_anchors * c.num_classes * (int)sizeof(float);   // multiple of 64
-    h->sf_ndma = dma_bytes / 1024;            // full 1 KiB LDS-DMA pieces ...
-    h->sf_rem = (dma_bytes % 1024) / 16;      // ... and the lanes of the last, partial one
-    h->sf_bufb = (row_bytes + 15) / 16 * 16;
-    if (h->sf_nbuf * h->sf_bufb + 2048 <= 64 * 1024 || h->tile_anchors == 16) break;
-    h->tile_anchors /= 2;
-  }
-  if (!h->sf_stg && h->sf_nbuf * h->sf_bufb + 2048 > 64 * 1024) h->sf_nbuf = 2;
-
-  h->ntiles = (c.num_anchors + h->tile_anchors - 1) / h->tile_anchors;
-  const size_t B = (size_t)c.max_batch, A = (size_t)c.num_anchors, nseg = (size_t)h->nseg;
+  h->sf_bufb = (YP_SF_TA * h->lds_stride * (int)sizeof(float) + 15) / 16 * 16;
+  h->ntiles = (c.num_anchors + YP_SF_TA - 1) / YP_SF_TA;
+  h->sf_waves_per_cu = yp_score_filter_waves_per_cu(h);
   const bool per_class = c.nms_mode == YP_NMS_PER_CLASS;
-  const size_t cand_per_img = per_class ? nseg * A : (size_t)h->ntiles * h->tile_anchors;
+  {
+    // Sum of probabilities <= 1 (+ rounding), so fewer than 1/conf classes of one anchor exceed conf.
+    int kpa = 1;
+    if (per_class) {
+      kpa = c.num_classes - 1;
+      if (c.conf_thresh > 0.0f) {
+        const double lim = floor(1.0 / (double)c.conf_thresh) + 1.0;
+        if (lim < (double)kpa) kpa = (int)lim;
+      }
+    }
+    h->keys_per_anchor = kpa;
+  }
+  const size_t B = (size_t)c.max_batch, nseg = (size_t)h->nseg;
+  size_t cand_keys = 0, max_items = 0;   // the largest any batch size up to max_batch needs
+  for (int bs = 1; bs <= c.max_batch; ++bs) {
+    int parts; long long cap;
+    yp_plan_items(h, bs, &parts, &cap);
+    const size_t items = (size_t)bs * parts;
+    if (items * (size_t)cap > cand_keys) cand_keys = items * (size_t)cap;
+    if (items > max_items) max_items = items;
+  }
   const size_t pool_per_img = per_class ? nseg * (size_t)c.top_k : 0;
   size_t off = 0;
-  const size_t o_cand = off;  off = align_up(off + B * cand_per_img * sizeof(u64), 256);
+  const size_t o_cand = off;  off = align_up(off + cand_keys * sizeof(u64), 256);
   const size_t o_pool = off;  off = align_up(off + B * pool_per_img * sizeof(u64), 256);
   const size_t o_crop = off;  off = align_up(off + B * h->sel_rows * sizeof(float4), 256);
   const size_t o_coef = off;  off = align_up(off + B * h->sel_rows * YP_MASK_DIM * sizeof(float), 256);
   const size_t o_cnt = off;   // all counters contiguous so one memset clears them
-  const size_t n_cnt = 2 * B * nseg + B * (size_t)h->ntiles + B;
+  const size_t n_cnt = 2 * max_items + B * nseg + B;
   off = align_up(off + n_cnt * sizeof(int32_t), 256);
   h->scratch_bytes = (int64_t)off;
   if (hipMalloc(&h->scratch_base, off) != hipSuccess) {
@@ -119,19 +114,16 @@ extern "C" int yp_create(const yp_config* cfg, yp_handle** out) {
   h->s.pool = (u64*)(base + o_pool);
   h->s.crop = (float4*)(base + o_crop);
   h->s.coef = (float*)(base + o_coef);
-  h->s.cand_count = (int32_t*)(base + o_cnt);
-  h->s.pool_count = h->s.cand_count + B * nseg;
-  h->s.tile_count = h->s.pool_count + B * nseg;
-  h->s.stat_surv = h->s.tile_count + B * (size_t)h->ntiles;
-  if (hipMemset(h->s.cand_count, 0, n_cnt * sizeof(int32_t)) != hipSuccess) {
+  h->s.seg_count = (int32_t*)(base + o_cnt);
+  h->s.seg_surv = h->s.seg_count + max_items;
+  h->s.pool_count = h->s.seg_surv + max_items;
+  h->s.stat_surv = h->s.pool_count + B * nseg;
+  if (hipMemset(h->s.seg_count, 0, n_cnt * sizeof(int32_t)) != hipSuccess) {
     (void)hipFree(h->scratch_base);
     delete h;
     return fail(YP_EHIP, "hipMemset of the counters failed");
   }
-  (void)hipDeviceSynchronize();   // the counters are zero before any stream can run score_filter
-#ifdef YP_SF_STAMPS
-  (void)hipMalloc(&h->dbg, 2 * 64 * 65536); (void)hipMemset(h->dbg, 0, 2 * 64 * 65536);
-#endif
+  (void)hipDeviceSynchronize();
   *out = h;
   g_err[0] = 0;
   return YP_OK;
@@ -141,37 +133,6 @@ extern "C" int yp_destroy(yp_handle* h) {
   if (!h) return YP_OK;
   (void)hipSetDevice(h->cfg.device_id);
   (void)hipDeviceSynchronize();
-#ifdef YP_SF_STAMPS
-  {
-    unsigned long long* all = (unsigned long long*)malloc(64 * 65536);
-    (void)hipMemcpy(all, h->dbg, 64 * 65536, hipMemcpyDeviceToHost);
-    unsigned long long d[8] = {0};
-    for (int w = 0; w < 65536; ++w) for (int i = 0; i < 7; ++i) d[i] += all[w * 8 + i];
-    {
-      std::vector<double> life, comp, tiles;
-      for (int w = 0; w < 65536; ++w) if (all[w * 8 + 5]) { life.push_back((double)all[w * 8 + 7]); comp.push_back((double)(all[w * 8 + 2] + all[w * 8 + 3])); tiles.push_back((double)all[w * 8 + 5]); }
-      auto pct = [](std::vector<double> v, const char* name) {
-        if (v.empty()) return; std::sort(v.begin(), v.end()); const size_t n = v.size();
-        fprintf(stderr, "[yp stamps] per-wave %s: n=%zu min=%.0f p10=%.0f p50=%.0f p90=%.0f max=%.0f\n", name, n, v[0], v[n / 10], v[n / 2], v[n * 9 / 10], v[n - 1]);
-      };
-      pct(life, "lifetime"); pct(comp, "phase1+2 cycles"); pct(tiles, "tiles");
-    }
-    free(all);
-    const double n = d[5] ? (double)d[5] : 1.0;
-    fprintf(stderr, "[yp stamps] tiles=%llu phase0(wait+issue)=%.0f of which wait=%.0f phase1=%.0f phase2=%.0f dma_issue=%.0f cycles/tile npass=%.2f\n", d[5], d[0]/n, d[1]/n, d[2]/n, d[3]/n, d[4]/n, d[6]/n);
-    {
-      unsigned long long* nm = (unsigned long long*)malloc(64 * 65536);
-      (void)hipMemcpy(nm, (char*)h->dbg + 64 * 65536, 64 * 65536, hipMemcpyDeviceToHost);
-      for (int part = 0; part < 2; ++part) {
-        unsigned long long dsum[8] = {0}; int cnt = 0;
-        for (int w = part * 32768; w < (part + 1) * 32768; ++w) if (nm[w * 8 + 7]) { ++cnt; for (int i = 0; i < 7; ++i) dsum[i] += nm[w * 8 + i]; }
-        if (cnt) fprintf(stderr, "[yp stamps] %s blocks=%d  t1=%.0f t2=%.0f t3=%.0f t4=%.0f t5=%.0f t6=%.0f cycles/block (cumulative from kernel entry) n=%.1f\n", part ? "final_select" : "segment_nms", cnt, dsum[0]/(double)cnt, dsum[1]/(double)cnt, dsum[2]/(double)cnt, dsum[3]/(double)cnt, dsum[4]/(double)cnt, dsum[5]/(double)cnt, dsum[6]/(double)cnt);
-      }
-      free(nm);
-    }
-    (void)hipFree(h->dbg);
-  }
-#endif
   if (h->profile) for (int i = 0; i <= YP_NUM_KERNELS; ++i) (void)hipEventDestroy(h->ev[i]);
   (void)hipFree(h->scratch_base);
   delete h;

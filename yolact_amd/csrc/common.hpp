@@ -108,12 +108,13 @@ __device__ __forceinline__ void yp_sanitize(float a, float b, float img_size, bo
 #endif  // __HIPCC__
 
 // ---- device scratch owned by a handle -----------------------------------------------------
+#define YP_SF_TA 32   // anchors per score_filter tile
+
 struct yp_scratch {
-  u64* cand;            // cross-class: [max_batch][ntiles*TA] tile-major slots (tile g keeps its
-                        // tile_count[g] keys at the front of its TA slots);
-                        // per-class: [max_batch][nseg][A] append lists, unordered
-  int32_t* cand_count;  // per-class: [max_batch][nseg] list lengths (zero between runs: class_nms resets)
-  int32_t* tile_count;  // [max_batch][ntiles] survivors per score_filter tile (rewritten every run)
+  u64* cand;            // [nitems][cap_item] candidate keys: score_filter item i (image i / parts, part
+                        // i % parts) keeps seg_count[i] keys at the front of its list; unordered
+  int32_t* seg_count;   // [nitems] (rewritten every run)
+  int32_t* seg_surv;    // [nitems] anchors past the confidence filter (rewritten every run)
   int32_t* stat_surv;   // [max_batch] anchors past the confidence filter, for yp_last_survivors
   u64* pool;            // [max_batch][nseg][top_k] per-class NMS survivors (per-class mode)
   int32_t* pool_count;  // [max_batch][nseg] (rewritten every run)
@@ -127,15 +128,11 @@ struct yp_handle {
   int sel_rows;         // min(max_dets, YP_SORT_MAX): rows a detection can land in
   int lds_stride;       // floats per anchor row in score_filter's LDS tile
   float pre_thresh;     // score_filter's early-reject bound on x_bg - x_fgmax
-  int tile_anchors;     // TA: anchors per score_filter wave (16, 32 or 64)
-  int ntiles;           // ceil(A / TA)
+  int ntiles;           // ceil(A / YP_SF_TA)
   int num_cus;          // compute units of the device (256 on MI355X)
-  int sf_ndma, sf_rem;  // score_filter: full 1 KiB LDS-DMA pieces per tile + lanes of the partial last piece
-  int sf_stg;           // score_filter: 1 = the tile in flight is staged in VGPRs (one LDS buffer per wave)
-  int sf_bufb, sf_nbuf; // score_filter: bytes per LDS tile buffer, buffers per wave (prefetch distance + 1)
-#ifdef YP_SF_STAMPS
-  void* dbg;            // diagnostic build only
-#endif
+  int sf_bufb;          // score_filter: bytes of a wave's LDS tile buffer
+  int sf_waves_per_cu;  // score_filter: single-wave workgroups resident per CU
+  int keys_per_anchor;  // most keys one anchor can emit: 1 (cross-class) or min(C-1, floor(1/conf)+1)
   void* scratch_base;
   int64_t scratch_bytes;
   yp_scratch s;
@@ -144,6 +141,19 @@ struct yp_handle {
   int profile;
   hipEvent_t ev[YP_NUM_KERNELS + 1];
 };
+
+// How score_filter cuts a batch into work items (and where the NMS kernels find their lists):
+// `parts` items per image, as many as keep every item resident at once, each a run of consecutive
+// tiles; an item's list holds at most cap_item keys.
+static inline void yp_plan_items(const yp_handle* h, int batch, int* parts, long long* cap_item) {
+  const int resident = h->num_cus * h->sf_waves_per_cu;
+  int pt = batch > 0 ? resident / batch : 1;
+  pt = pt < 1 ? 1 : (pt > h->ntiles ? h->ntiles : pt);
+  *parts = pt;
+  *cap_item = (long long)((h->ntiles + pt - 1) / pt) * YP_SF_TA * h->keys_per_anchor;
+}
+
+int yp_score_filter_waves_per_cu(const yp_handle* h);
 
 // Kernel launchers (one per translation unit).  All asynchronous on `st`.
 hipError_t yp_launch_score_filter(const yp_handle* h, int batch, const float* pred_cls, hipStream_t st);

@@ -20,9 +20,9 @@
 #define YP_STAGE_CAP 4096
 
 struct NmsArgs {
-  const u64* cand;            // cross-class: [B, ntiles*TA] slots; per-class: [B,nseg,A] lists
-  int32_t* cand_count;        // per-class: [B,nseg]
-  const int32_t* tile_count;  // [B,ntiles]
+  const u64* cand;            // [B*parts][cap_item] score_filter's lists (common.hpp, yp_scratch)
+  const int32_t* seg_count;   // [B*parts] keys per list
+  const int32_t* seg_surv;    // [B*parts] anchors past the confidence filter per list
   int32_t* stat_surv;         // [B]
   const float4* off;          // [B,A] pred_offset (dx,dy,dw,dh)
   const float4* priors;       // [A]   (ymin,xmin,ymax,xmax) pixels
@@ -36,22 +36,11 @@ struct NmsArgs {
   float* det_scores;          // [B,max_dets]
   int32_t* num_det;           // [B]
   int32_t* kept_idx;          // [B,max_dets] (nullable)
-  int A, nseg, top_k, max_dets, sel_rows, ntiles, TA;
+  int A, nseg, top_k, max_dets, sel_rows, parts;
+  long long cap_item;
   float nms_thresh, img_h, img_w, proto_h, proto_w;
   int use_crop;
-#ifdef YP_SF_STAMPS
-  unsigned long long* dbg;
-#endif
 };
-#ifdef YP_SF_STAMPS
-#define NSTAMP(i) do { if (threadIdx.x == 0) dbgo[i] = (unsigned long long)(clock64() - T00); } while (0)
-#define NSTAMP_BEGIN(blk, nval) const long long T00 = clock64(); unsigned long long* dbgo = p.dbg + (size_t)(blk) * 8; 
-#define NSTAMP_END(nval) do { if (threadIdx.x == 0) { dbgo[6] = (unsigned long long)(nval); dbgo[7] = 1; } } while (0)
-#else
-#define NSTAMP(i)
-#define NSTAMP_BEGIN(blk, nval)
-#define NSTAMP_END(nval)
-#endif
 
 struct SelectShared {
   u64 key[YP_SORT_MAX];    // result: selected keys, sorted descending
@@ -68,6 +57,7 @@ struct SelectShared {
 // batches of YP_SRC_UNROLL independent, unconditional loads (slots past a group's count hold stale
 // keys and are simply skipped) so that one memory round trip serves a whole batch.
 #define YP_SRC_UNROLL 4
+#define YP_PART_UNROLL 8
 struct ListSrc {   // n contiguous keys (global or LDS)
   const u64* list;
   int n;
@@ -106,6 +96,33 @@ struct SlotSrc {   // nsegs groups of `per` slots; group g holds counts[g] keys 
 #pragma unroll
       for (int u = 0; u < YP_SRC_UNROLL; ++u)
         if (s0 + u * THREADS < total && room[u] > 0) f(k[u]);
+    }
+  }
+};
+
+struct PartSrc {   // score_filter's lists of one image: nparts lists of `cap` slots, list j holds counts[j] keys
+  const u64* base;
+  const int32_t* counts;
+  int nparts;
+  long long cap;
+  int cls;           // 0: every key; otherwise only the keys of this class (per-class mode)
+  template <int THREADS, class F>
+  __device__ __forceinline__ void for_each(F f) const {
+    int sft = 0;     // 1 << sft threads share a list: as many as the workgroup has to spare
+    while ((2 << sft) * nparts <= THREADS && sft < 6) ++sft;
+    const int lpp = 1 << sft;
+    for (int s = threadIdx.x; s < (nparts << sft); s += THREADS) {
+      const int j = s >> sft, q = s & (lpp - 1);
+      const int n = counts[j];
+      const u64* l = base + (size_t)j * cap;
+      for (int i0 = q; i0 < n; i0 += lpp * YP_PART_UNROLL) {
+        u64 k[YP_PART_UNROLL];
+#pragma unroll
+        for (int u = 0; u < YP_PART_UNROLL; ++u) k[u] = l[min(i0 + u * lpp, n - 1)];
+#pragma unroll
+        for (int u = 0; u < YP_PART_UNROLL; ++u)
+          if (i0 + u * lpp < n && (cls == 0 || yp_seg_key_class(k[u]) == cls)) f(k[u]);
+      }
     }
   }
 };
@@ -379,15 +396,15 @@ __global__ __launch_bounds__(THREADS) void cc_nms_kernel(const NmsArgs p) {
   __shared__ int s_wave_cnt[YP_SORT_MAX / YP_WAVE];
   const int t = threadIdx.x;
   const int b = blockIdx.x;
-  const int32_t* counts = p.tile_count + (size_t)b * p.ntiles;
+  const int32_t* counts = p.seg_count + (size_t)b * p.parts;
   int part = 0;
-  for (int i = t; i < p.ntiles; i += THREADS) part += counts[i];
+  for (int i = t; i < p.parts; i += THREADS) part += counts[i];
   const int n = block_sum<THREADS>(part, sh.wtot);            // survivors of the confidence filter
   if (n == 0) {                                                // detection.py:81
     finish_image<THREADS>(p, b, 0, s_anchor, 0);
     return;
   }
-  const SlotSrc src{p.cand + (size_t)b * p.ntiles * p.TA, counts, p.ntiles, p.TA};
+  const PartSrc src{p.cand + (size_t)b * p.parts * p.cap_item, counts, p.parts, p.cap_item, 0};
   const int k = select_topk_sorted<THREADS>(src, n, p.top_k, sh, stage);       // detection.py:186
   float4 mybox = make_float4(0.f, 0.f, 0.f, 0.f);
   if (t < YP_SORT_MAX) {
@@ -422,45 +439,44 @@ __global__ __launch_bounds__(THREADS) void class_nms_kernel(const NmsArgs p) {
   const int t = threadIdx.x;
   const int seg = blockIdx.x, b = blockIdx.y;
   const size_t sidx = (size_t)b * p.nseg + seg;
-  NSTAMP_BEGIN(sidx, 0)
-  const u64* list = p.cand + sidx * p.A;
-  // the count and (speculatively) the first 256 keys travel together
-  const int n = min(p.cand_count[sidx], p.A);
-  const u64 kspec = list[min(t, p.A - 1)];
+  // This class's candidates: one pass over the image's lists (a few tens of KB, shared by the
+  // image's C-1 workgroups through L2), keys of other classes skipped.
+  const PartSrc src{p.cand + (size_t)b * p.parts * p.cap_item, p.seg_count + (size_t)b * p.parts, p.parts, p.cap_item, seg + 1};
+  if (t == 0) sh.fill = 0;
+  if (t < YP_SORT_MAX) { smax[t] = 0; sh.rank[t] = 0; }
   __syncthreads();
-  NSTAMP(0);
-  if (t == 0) p.cand_count[sidx] = 0;   // leave the counter ready for the next run
+  src.template for_each<THREADS>([&](u64 key) {
+    const int q = atomicAdd(&sh.fill, 1);
+    if (q < YP_SORT_MAX) sh.tmp[q] = key;
+  });
+  __syncthreads();
+  const int n = sh.fill;
   if (n == 0) {
     if (t == 0) p.pool_count[sidx] = 0;
     return;
   }
   int k;
-  if (t < YP_SORT_MAX) { smax[t] = 0; sh.rank[t] = 0; }
   if (n <= YP_SORT_MAX) {
     // Every candidate's box is fetched and decoded while its rank (= number of larger keys) is
     // counted; key and box then go straight to their sorted position.
     const bool have = t < n;
     float4 pr = make_float4(0.f, 0.f, 0.f, 0.f), of = pr;
+    u64 mine = 0;
     if (have) {
-      const int a = min(yp_seg_key_anchor(kspec), p.A - 1);
+      mine = sh.tmp[t];
+      const int a = min(yp_seg_key_anchor(mine), p.A - 1);
       pr = p.priors[a];
       of = p.off[(size_t)b * p.A + a];
-      sh.tmp[t] = kspec;
-    }
-    __syncthreads();
-    NSTAMP(1);
-    if (have) {
       int r = 0;
-      for (int i = 0; i < n; ++i) r += sh.tmp[i] > kspec ? 1 : 0;
-      sh.key[r] = kspec;
+      for (int i = 0; i < n; ++i) r += sh.tmp[i] > mine ? 1 : 0;
+      sh.key[r] = mine;
       sbox[r] = yp_decode(pr, of);                                                      // detection.py:79
     }
     k = min(p.top_k, n);
     __syncthreads();
-    NSTAMP(2);
   } else {
-    const ListSrc ls{list, n};
-    k = select_topk_sorted<THREADS>(ls, n, p.top_k, sh, nullptr);                 // detection.py:217
+    __syncthreads();   // everybody has read sh.fill
+    k = select_topk_sorted<THREADS>(src, n, p.top_k, sh, nullptr);                // detection.py:217
     if (t < YP_SORT_MAX) {
       if (t < k) {                                                                      // detection.py:219
         const int a = min(yp_seg_key_anchor(sh.key[t]), p.A - 1);   // (clamp: never index out of bounds)
@@ -471,15 +487,12 @@ __global__ __launch_bounds__(THREADS) void class_nms_kernel(const NmsArgs p) {
   }
   int pos, total;
   const bool keep = fast_nms_keep<THREADS>(sbox, smax, s_wave_cnt, k, p.nms_thresh, pos, total);
-  NSTAMP(3);
   // class-major pool of survivors for the cross-class top-N               (detection.py:234-239)
   if (keep) {
     const u64 key = sh.key[t];
     p.pool[sidx * p.top_k + pos] = yp_fin_key(yp_key_score(key), yp_seg_key_anchor(key), seg + 1);
   }
   if (t == 0) p.pool_count[sidx] = total;
-  NSTAMP(4);
-  NSTAMP_END(n);
 }
 
 // Per-class mode only: cross-class top max_dets over the pooled survivors (detection.py:242-248).
@@ -490,20 +503,17 @@ __global__ __launch_bounds__(THREADS) void final_select_kernel(const NmsArgs p) 
   __shared__ int s_anchor[YP_SORT_MAX];
   const int t = threadIdx.x;
   const int b = blockIdx.x;
-  NSTAMP_BEGIN(32768 + b, 0)
   const int32_t* counts = p.pool_count + (size_t)b * p.nseg;
   int part = 0;
   for (int i = t; i < p.nseg; i += THREADS) part += counts[i];
   const int n = block_sum<THREADS>(part, sh.wtot);
   part = 0;
-  for (int i = t; i < p.ntiles; i += THREADS) part += p.tile_count[(size_t)b * p.ntiles + i];
+  for (int i = t; i < p.parts; i += THREADS) part += p.seg_surv[(size_t)b * p.parts + i];
   const int survivors = block_sum<THREADS>(part, sh.wtot);
-  NSTAMP(0);
   int k = 0;
   if (n > 0) {
     const SlotSrc src{p.pool + (size_t)b * p.nseg * p.top_k, counts, p.nseg, p.top_k};
     k = select_topk_sorted<THREADS>(src, n, min(p.max_dets, YP_SORT_MAX), sh, stage);
-    NSTAMP(3);
     if (t < k) {
       const u64 key = sh.key[t];
       const int anchor = min(yp_fin_key_anchor(key), p.A - 1);
@@ -512,31 +522,26 @@ __global__ __launch_bounds__(THREADS) void final_select_kernel(const NmsArgs p) 
                yp_decode(p.priors[anchor], p.off[(size_t)b * p.A + anchor]));
     }
     __syncthreads();
-    NSTAMP(4);
   }
   finish_image<THREADS>(p, b, k, s_anchor, survivors);
-  NSTAMP(5);
-  NSTAMP_END(n);
 }
 
-static NmsArgs make_args(const yp_handle* h, const float* pred_offset, const float* priors, const float* pred_mask_coef, float* det_boxes, float* det_classes,
+static NmsArgs make_args(const yp_handle* h, int batch, const float* pred_offset, const float* priors, const float* pred_mask_coef, float* det_boxes, float* det_classes,
                          float* det_scores, int32_t* num_det, int32_t* kept_idx) {
   NmsArgs a;
-  a.cand = h->s.cand; a.cand_count = h->s.cand_count; a.tile_count = h->s.tile_count; a.stat_surv = h->s.stat_surv;
+  a.cand = h->s.cand; a.seg_count = h->s.seg_count; a.seg_surv = h->s.seg_surv; a.stat_surv = h->s.stat_surv;
   a.off = reinterpret_cast<const float4*>(pred_offset); a.priors = reinterpret_cast<const float4*>(priors);
   a.pool = h->s.pool; a.pool_count = h->s.pool_count; a.crop = h->s.crop;
   a.coef_out = h->s.coef; a.coef_in = pred_mask_coef;
   a.det_boxes = det_boxes; a.det_classes = det_classes; a.det_scores = det_scores; a.num_det = num_det;
   a.kept_idx = kept_idx;
   a.A = h->cfg.num_anchors; a.nseg = h->nseg; a.top_k = h->cfg.top_k; a.max_dets = h->cfg.max_dets;
-  a.sel_rows = h->sel_rows; a.ntiles = h->ntiles; a.TA = h->tile_anchors;
+  a.sel_rows = h->sel_rows;
   a.nms_thresh = h->cfg.nms_thresh;
   a.img_h = (float)h->cfg.img_h; a.img_w = (float)h->cfg.img_w;
   a.proto_h = (float)h->cfg.proto_h; a.proto_w = (float)h->cfg.proto_w;
   a.use_crop = h->cfg.use_cropped_mask;
-#ifdef YP_SF_STAMPS
-  a.dbg = (unsigned long long*)((char*)h->dbg + 64 * 65536);
-#endif
+  yp_plan_items(h, batch, &a.parts, &a.cap_item);
   return a;
 }
 
@@ -544,7 +549,7 @@ hipError_t yp_launch_segment_nms(const yp_handle* h, int batch, const float* pre
                                  const float* pred_mask_coef, float* det_boxes,
                                  float* det_classes, float* det_scores, int32_t* num_det, int32_t* kept_idx,
                                  hipStream_t st) {
-  const NmsArgs a = make_args(h, pred_offset, priors, pred_mask_coef, det_boxes, det_classes, det_scores, num_det, kept_idx);
+  const NmsArgs a = make_args(h, batch, pred_offset, priors, pred_mask_coef, det_boxes, det_classes, det_scores, num_det, kept_idx);
   if (h->cfg.nms_mode == YP_NMS_CROSS_CLASS)
     hipLaunchKernelGGL((cc_nms_kernel<1024>), dim3(batch), dim3(1024), 0, st, a);
   else
@@ -556,7 +561,7 @@ hipError_t yp_launch_final_select(const yp_handle* h, int batch, const float* pr
                                   const float* pred_mask_coef, float* det_boxes,
                                   float* det_classes, float* det_scores, int32_t* num_det, int32_t* kept_idx,
                                   hipStream_t st) {
-  const NmsArgs a = make_args(h, pred_offset, priors, pred_mask_coef, det_boxes, det_classes, det_scores, num_det, kept_idx);
+  const NmsArgs a = make_args(h, batch, pred_offset, priors, pred_mask_coef, det_boxes, det_classes, det_scores, num_det, kept_idx);
   hipLaunchKernelGGL((final_select_kernel<1024>), dim3(batch), dim3(1024), 0, st, a);
   return hipGetLastError();
 }
