@@ -57,6 +57,8 @@ def main():
     ap.add_argument("--batch", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=16)
+    ap.add_argument("--inflight", type=int, default=1,
+                    help="batches in flight: N handles on N HIP streams taking the steps in turn")
     ap.add_argument("--timed-events", type=int, default=0,
                     help="1: the timed region records the per-kernel HIP events too (costs ~4%%); "
                          "0 (default): `value` is timed without events and the same K steps are then "
@@ -99,15 +101,33 @@ def main():
         torch.cuda.synchronize(dev)
 
     pp.profile(bool(args.timed_events))   # HIP events around every kernel, recorded on the launch stream
-    for _ in range(args.warmup):
-        pp.run(*ins, out=out)
+    NF = max(1, args.inflight)
+    pps = [pp] + [PostProcessor(pc) for _ in range(NF - 1)]
+    outs = [out] + [pp.alloc_outputs(B) for _ in range(NF - 1)]
+    if NF > 1:
+        insl = [ins]
+        for f in range(1, NF):   # every slot streams its own images
+            netf, _ = synth.make_batch(cfg, batch=B, first_image=(rank * NF + f) * B + 1000)
+            df = {k: torch.from_numpy(v).to(dev) for k, v in netf.items()}
+            insl.append((df["pred_offset"], df["pred_cls"], df["pred_mask_coef"], d["priors"], df["proto_out"]))
+        streams = [torch.cuda.Stream(dev) for _ in range(NF)]
+    else:
+        insl, streams = [ins], [torch.cuda.current_stream(dev)]
+
+    def step(i):
+        f = i % NF
+        with torch.cuda.stream(streams[f]):
+            pps[f].run(*insl[f], out=outs[f])
+
+    for i in range(args.warmup):
+        step(i)
     barrier()
     if os.environ.get("YP_SF_ABL_AFTER_WARMUP"):   # diagnostic builds only (tools/sf_ablate.sh)
         os.environ["YP_SF_ABL"] = os.environ["YP_SF_ABL_AFTER_WARMUP"]
     kern_ms = {}
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        pp.run(*ins, out=out)
+    for i in range(args.steps):
+        step(i)
         # reading the events of step i while step i+1.. are not yet queued would serialise the host;
         # instead each step's events are read back after the loop for the LAST step only, and the
         # per-kernel averages come from the second, instrumented region below.

@@ -95,7 +95,9 @@ extern "C" int yp_create(const yp_config* cfg, yp_handle** out) {
     if (items * (size_t)cap > cand_keys) cand_keys = items * (size_t)cap;
     if (items > max_items) max_items = items;
   }
-  const size_t pool_per_img = per_class ? nseg * (size_t)c.top_k : 0;
+  int ngroups, gcap;
+  yp_plan_groups(h, &ngroups, &gcap);
+  const size_t pool_per_img = per_class ? (size_t)ngroups * gcap : 0;
   size_t off = 0;
   const size_t o_cand = off;  off = align_up(off + cand_keys * sizeof(u64), 256);
   const size_t o_pool = off;  off = align_up(off + B * pool_per_img * sizeof(u64), 256);

@@ -116,8 +116,8 @@ struct yp_scratch {
   int32_t* seg_count;   // [nitems] (rewritten every run)
   int32_t* seg_surv;    // [nitems] anchors past the confidence filter (rewritten every run)
   int32_t* stat_surv;   // [max_batch] anchors past the confidence filter, for yp_last_survivors
-  u64* pool;            // [max_batch][nseg][top_k] per-class NMS survivors (per-class mode)
-  int32_t* pool_count;  // [max_batch][nseg] (rewritten every run)
+  u64* pool;            // [max_batch][ngroups][gcap] per-class NMS survivors (per-class mode), dense per class group
+  int32_t* pool_count;  // [max_batch][ngroups] (rewritten every run)
   float4* crop;         // [max_batch][sel_rows] (x1,x2,y1,y2) crop edges in proto pixels
   float* coef;          // [max_batch][sel_rows][32] coefficients of the kept detections
 };
@@ -151,6 +151,14 @@ static inline void yp_plan_items(const yp_handle* h, int batch, int* parts, long
   pt = pt < 1 ? 1 : (pt > h->ntiles ? h->ntiles : pt);
   *parts = pt;
   *cap_item = (long long)((h->ntiles + pt - 1) / pt) * YP_SF_TA * h->keys_per_anchor;
+}
+
+// Per-class mode: the classes of an image are dealt round-robin to `ngroups` workgroups; a group's
+// pool list holds at most gcap keys (top_k per class).
+static inline void yp_plan_groups(const yp_handle* h, int* ngroups, int* gcap) {
+  const int ng = h->nseg < 16 ? h->nseg : 16;
+  *ngroups = ng;
+  *gcap = ((h->nseg + ng - 1) / ng) * h->cfg.top_k;
 }
 
 int yp_score_filter_waves_per_cu(const yp_handle* h);

@@ -1,23 +1,31 @@
-// Kernels 2+3: top-k selection + Fast NMS per segment, and the final detection rows.
+// Kernels 2+3: top-k selection + Fast NMS, and the final detection rows.
 //
 // Replaces detection.py:186-207 (_cc_fast_nms: top_k, gather, pairwise IoU, strict upper triangle,
 // column max, threshold, gathers), detection.py:217-248 (the per-class intent of _fast_nms),
-// detection.py:92-98 (_sanitize + normalise), the edge computation of utils.crop
-// (utils/utils.py:116-117) and the box/class/score scatters of detection.py:109-114.
+// utils._decode for the candidates that get this far (utils/utils.py:173-213), detection.py:92-98
+// (_sanitize + normalise), the edge computation of utils.crop (utils/utils.py:116-117) and the
+// box/class/score scatters of detection.py:109-114.
 //
-// A "segment" is one image (cross-class mode) or one (image, class) pair (per-class mode).  One
-// workgroup owns a segment: it selects the top_k candidate keys (MSB-first radix select on the
-// 64-bit keys when the segment holds more than 256, staged in LDS when they fit), sorts them with
-// a bitonic network in LDS, gathers the <= 256 decoded boxes into LDS and lets thread j reduce
-// max_{i<j} IoU(i,j) in registers - the k x k IoU matrix (160 KB at k=200) is never materialised.
-// max is order independent, so the result equals the reference's reduce_max over the strict upper
-// triangle.  Latency-bound kernels: no returning global atomics, candidate and box loads are issued
-// as early as their addresses are known.
+// These kernels are latency, not bandwidth: a few thousand 8-byte keys per image.  What they are
+// built around is the number of DEPENDENT global round trips (each 1-2 us under load) and the fact
+// that one CU moves only ~10-25 bytes per clock, so an image's work is spread over several
+// workgroups wherever it is more than a few KB:
+//   cross-class  cc_nms_kernel: one workgroup per image (top_k <= 256 boxes reach the NMS)
+//   per-class    group_nms_kernel: 16 workgroups per image, each owning the classes c with
+//                (c-1) % 16 == g; all of a group's candidates are bucketed by class in LDS and
+//                ranked, decoded and suppressed thread-per-candidate;
+//                final_select_kernel: one workgroup per image, cross-class top max_dets
+// The k x k IoU matrix (160 KB at k=200) is never materialised: the reference's reduce_max over the
+// strict upper triangle followed by `<= threshold` is "no higher-ranked box overlaps more than the
+// threshold", evaluated pair by pair.
 #include "common.hpp"
 
 #define YP_RADIX_BITS 11
 #define YP_RADIX_BINS (1 << YP_RADIX_BITS)
 #define YP_STAGE_CAP 4096
+#define YP_GROUP_CAP 1024    // candidates of one class group that the thread-per-candidate path takes
+#define YP_GROUP_THREADS 512
+#define YP_GROUP_KPT (YP_GROUP_CAP / YP_GROUP_THREADS)
 
 struct NmsArgs {
   const u64* cand;            // [B*parts][cap_item] score_filter's lists (common.hpp, yp_scratch)
@@ -26,8 +34,8 @@ struct NmsArgs {
   int32_t* stat_surv;         // [B]
   const float4* off;          // [B,A] pred_offset (dx,dy,dw,dh)
   const float4* priors;       // [A]   (ymin,xmin,ymax,xmax) pixels
-  u64* pool;                  // [B,nseg,top_k] per-class NMS survivors, final-key format
-  int32_t* pool_count;        // [B,nseg]
+  u64* pool;                  // [B,ngroups,gcap] per-class NMS survivors, final-key format, dense per group
+  int32_t* pool_count;        // [B,ngroups]
   float4* crop;               // [B,sel_rows]
   float* coef_out;            // [B,sel_rows,32]
   const float* coef_in;       // [B,A,32]
@@ -36,7 +44,7 @@ struct NmsArgs {
   float* det_scores;          // [B,max_dets]
   int32_t* num_det;           // [B]
   int32_t* kept_idx;          // [B,max_dets] (nullable)
-  int A, nseg, top_k, max_dets, sel_rows, parts;
+  int A, nseg, top_k, max_dets, sel_rows, parts, ngroups, gcap;
   long long cap_item;
   float nms_thresh, img_h, img_w, proto_h, proto_w;
   int use_crop;
@@ -54,8 +62,7 @@ struct SelectShared {
 
 // ---- key sources ---------------------------------------------------------------------------
 // for_each visits every key once, spread over the workgroup's threads.  Loads are issued in
-// batches of YP_SRC_UNROLL independent, unconditional loads (slots past a group's count hold stale
-// keys and are simply skipped) so that one memory round trip serves a whole batch.
+// batches of independent loads so that one memory round trip serves a whole batch.
 #define YP_SRC_UNROLL 4
 #define YP_PART_UNROLL 8
 struct ListSrc {   // n contiguous keys (global or LDS)
@@ -76,36 +83,17 @@ struct ListSrc {   // n contiguous keys (global or LDS)
     }
   }
 };
-struct SlotSrc {   // nsegs groups of `per` slots; group g holds counts[g] keys at its front
-  const u64* slots;
-  const int32_t* counts;
-  int nsegs, per;
-  template <int THREADS, class F>
-  __device__ __forceinline__ void for_each(F f) const {
-    const int total = nsegs * per;
-    for (int s0 = threadIdx.x; s0 < total; s0 += THREADS * YP_SRC_UNROLL) {
-      u64 k[YP_SRC_UNROLL];
-      int room[YP_SRC_UNROLL];
-#pragma unroll
-      for (int u = 0; u < YP_SRC_UNROLL; ++u) {
-        const int s = min(s0 + u * THREADS, total - 1);
-        const int g = s / per;
-        k[u] = slots[s];
-        room[u] = counts[g] - (s - g * per);
-      }
-#pragma unroll
-      for (int u = 0; u < YP_SRC_UNROLL; ++u)
-        if (s0 + u * THREADS < total && room[u] > 0) f(k[u]);
-    }
-  }
-};
-
 struct PartSrc {   // score_filter's lists of one image: nparts lists of `cap` slots, list j holds counts[j] keys
   const u64* base;
   const int32_t* counts;
   int nparts;
   long long cap;
-  int cls;           // 0: every key; otherwise only the keys of this class (per-class mode)
+  int cls;           // > 0: only the keys of this class
+  int gmod, grem;    // gmod > 0: only the keys of classes c with (c - 1) % gmod == grem
+  __device__ __forceinline__ bool take(u64 k) const {
+    const int c = yp_seg_key_class(k);
+    return (cls == 0 || c == cls) && (gmod == 0 || (c - 1) % gmod == grem);
+  }
   template <int THREADS, class F>
   __device__ __forceinline__ void for_each(F f) const {
     int sft = 0;     // 1 << sft threads share a list: as many as the workgroup has to spare
@@ -121,11 +109,46 @@ struct PartSrc {   // score_filter's lists of one image: nparts lists of `cap` s
         for (int u = 0; u < YP_PART_UNROLL; ++u) k[u] = l[min(i0 + u * lpp, n - 1)];
 #pragma unroll
         for (int u = 0; u < YP_PART_UNROLL; ++u)
-          if (i0 + u * lpp < n && (cls == 0 || yp_seg_key_class(k[u]) == cls)) f(k[u]);
+          if (i0 + u * lpp < n && take(k[u])) f(k[u]);
       }
     }
   }
 };
+struct PoolSrc {   // ngroups lists of gcap slots; list g holds its keys at [0, start[g+1] - start[g])
+  const u64* base;
+  const int* start;   // LDS: exclusive prefix of the list lengths, ngroups + 1 entries
+  int ngroups, gcap;
+  template <int THREADS, class F>
+  __device__ __forceinline__ void for_each(F f) const {
+    const int n = start[ngroups];
+    for (int i0 = threadIdx.x; i0 < n; i0 += THREADS * YP_SRC_UNROLL) {
+      u64 k[YP_SRC_UNROLL];
+#pragma unroll
+      for (int u = 0; u < YP_SRC_UNROLL; ++u) {
+        const int i = min(i0 + u * THREADS, n - 1);
+        int g = 0;
+        while (start[g + 1] <= i) ++g;      // <= 16 groups
+        k[u] = base[(size_t)g * gcap + (i - start[g])];
+      }
+#pragma unroll
+      for (int u = 0; u < YP_SRC_UNROLL; ++u)
+        if (i0 + u * THREADS < n) f(k[u]);
+    }
+  }
+};
+
+// Slot in an LDS list for every calling lane: one LDS atomic per wave instead of one per lane (lanes
+// adding to one address are served one after the other).  May be called under divergence: the lanes
+// that are active together are counted together.
+__device__ __forceinline__ int lds_append_slot(int* counter) {
+  const u64 act = __ballot(1);
+  const int lane = threadIdx.x & 63;
+  const int leader = __ffsll((long long)act) - 1;
+  int base = 0;
+  if (lane == leader) base = atomicAdd(counter, __popcll(act));
+  base = __shfl(base, leader);
+  return base + __popcll(act & ((1ull << lane) - 1ull));
+}
 
 template <int THREADS>
 __device__ int block_sum(int v, int* wtot) {   // wtot: >= THREADS/64 ints of LDS
@@ -246,7 +269,7 @@ __device__ int select_topk_sorted(const Src& src, int n, int want, SelectShared&
   int m;
   if (n <= YP_SORT_MAX) {
     src.template for_each<THREADS>([&](u64 key) {
-      const int q = atomicAdd(&sh.fill, 1);
+      const int q = lds_append_slot(&sh.fill);
       if (q < YP_SORT_MAX) sh.tmp[q] = key;
     });
     m = n;
@@ -257,7 +280,7 @@ __device__ int select_topk_sorted(const Src& src, int n, int want, SelectShared&
       lo = key < lo ? key : lo;
       hi = key > hi ? key : hi;
       if (staged) {
-        const int q = atomicAdd(&sh.fill, 1);
+        const int q = lds_append_slot(&sh.fill);
         if (q < YP_STAGE_CAP) stage[q] = key;
       }
     });
@@ -278,7 +301,7 @@ __device__ int select_topk_sorted(const Src& src, int n, int want, SelectShared&
     if (superset <= YP_SORT_MAX) {
       auto take = [&](u64 key) {
         if ((int)((key >> shift) & dmask) >= sel) {
-          const int q = atomicAdd(&sh.fill, 1);
+          const int q = lds_append_slot(&sh.fill);
           if (q < YP_SORT_MAX) sh.tmp[q] = key;
         }
       };
@@ -290,7 +313,7 @@ __device__ int select_topk_sorted(const Src& src, int n, int want, SelectShared&
       if (staged) radix_select<THREADS>(ls, k, sh, prefix, mask); else radix_select<THREADS>(src, k, sh, prefix, mask);
       auto take = [&](u64 key) {
         if ((key & mask) >= prefix) {
-          const int q = atomicAdd(&sh.fill, 1);
+          const int q = lds_append_slot(&sh.fill);
           if (q < YP_SORT_MAX) sh.tmp[q] = key;
         }
       };
@@ -303,10 +326,33 @@ __device__ int select_topk_sorted(const Src& src, int n, int want, SelectShared&
   return k;
 }
 
-// Writes output row r of image b (detection.py:92-98, 110-112) and the row's crop edges
-// (utils/utils.py:116-117 with padding 1.0, normalised coordinates: SURVEY.md A12).
+// iou(a, b) > thr with utils._iou's arithmetic (utils/utils.py:19-21, 40-48, 63-70), without the
+// division wherever the answer cannot depend on its rounding: thr*union is within 2^-24 of exact, so
+// an intersection outside thr*union*(1 -+ 2^-21) is on one side of the threshold for any correctly
+// rounded quotient (the neighbours of thr are >= 2^-24 relative away).  In between - and for a
+// non-positive union - the reference's expression is evaluated as written.
+__device__ __forceinline__ bool yp_iou_gt(const float4 a, const float4 b, float thr) {
+  const float area1 = (a.z - a.x) * (a.w - a.y);
+  const float area2 = (b.z - b.x) * (b.w - b.y);
+  const float ih = fmaxf(0.0f, fminf(a.z, b.z) - fmaxf(a.x, b.x));
+  const float iw = fmaxf(0.0f, fminf(a.w, b.w) - fmaxf(a.y, b.y));
+  const float inter = ih * iw;
+  const float uni = (area1 + area2) - inter;
+  const float pr = thr * uni;
+  if (uni > 0.0f) {
+    if (inter > pr * (1.0f + 0x1p-21f)) return true;
+    if (inter < pr * (1.0f - 0x1p-21f)) return false;
+  }
+  return (inter == 0.0f ? 0.0f : inter / uni) > thr;
+}
+
+// Output row r of image b: sanitize + normalise (detection.py:92-98), class/score/index
+// (L110-112), the row's crop edges (utils/utils.py:116-117 with padding 1.0, normalised
+// coordinates: SURVEY.md A12) and its coefficient row, compacted for mask_assemble (L206).
+// `of`/`pr` are the anchor's offsets and prior, `cf` its 8 x float4 coefficient row: the caller
+// loads them together, in one round trip.
 __device__ __forceinline__ void emit_row(const NmsArgs& p, int b, int r, float score, int cls, int anchor,
-                                         const float4 bx /* ymin,xmin,ymax,xmax pixels */) {
+                                         const float4 bx /* ymin,xmin,ymax,xmax pixels */, const float4* cf) {
   float x1, x2, y1, y2;
   yp_sanitize(bx.y, bx.w, p.img_w, false, 0.0f, x1, x2);     // detection.py:126
   yp_sanitize(bx.x, bx.z, p.img_h, false, 0.0f, y1, y2);     // detection.py:127
@@ -325,18 +371,20 @@ __device__ __forceinline__ void emit_row(const NmsArgs& p, int b, int r, float s
     cb.x = 0.0f; cb.y = p.proto_w; cb.z = 0.0f; cb.w = p.proto_h;
   }
   p.crop[(size_t)b * p.sel_rows + r] = cb;
+  float4* co = reinterpret_cast<float4*>(p.coef_out + ((size_t)b * p.sel_rows + r) * YP_MASK_DIM);
+#pragma unroll
+  for (int q = 0; q < YP_MASK_DIM / 4; ++q) co[q] = cf[q];
+}
+__device__ __forceinline__ void load_coef(const NmsArgs& p, int b, int anchor, float4* cf) {
+  const float4* ci = reinterpret_cast<const float4*>(p.coef_in + ((size_t)b * p.A + anchor) * YP_MASK_DIM);
+#pragma unroll
+  for (int q = 0; q < YP_MASK_DIM / 4; ++q) cf[q] = ci[q];
 }
 
-// Rows [n, max_dets) of image b: zeros / -1 (detection.py:65-67); the kept detections' coefficient
-// rows, compacted for mask_assemble (detection.py:206); num_det (L114).
+// Rows [n, max_dets) of image b: zeros / -1 (detection.py:65-67); num_det (L114).
 template <int THREADS>
-__device__ void finish_image(const NmsArgs& p, int b, int n, const int* s_anchor, int survivors) {
+__device__ void finish_image(const NmsArgs& p, int b, int n, int survivors) {
   const int t = threadIdx.x;
-  for (int i = t; i < n * (YP_MASK_DIM / 4); i += THREADS) {
-    const int r = i / (YP_MASK_DIM / 4), q = i % (YP_MASK_DIM / 4);
-    const float4 v = reinterpret_cast<const float4*>(p.coef_in + ((size_t)b * p.A + s_anchor[r]) * YP_MASK_DIM)[q];
-    reinterpret_cast<float4*>(p.coef_out + ((size_t)b * p.sel_rows + r) * YP_MASK_DIM)[q] = v;
-  }
   for (int r = n + t; r < p.max_dets; r += THREADS) {
     const size_t o = (size_t)b * p.max_dets + r;
     reinterpret_cast<float4*>(p.det_boxes)[o] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -350,25 +398,26 @@ __device__ void finish_image(const NmsArgs& p, int b, int n, const int* s_anchor
   }
 }
 
-// iou_max[j] = max_{i<j} iou(i,j) over the k sorted boxes in sbox; keep = iou_max <= thr, order
-// preserved (detection.py:190-202).  Returns this thread's keep flag (threads < k) and its rank
-// among the kept ones in `pos`; `total` = number kept.  smax[] must be zero.  All threads must call it.
+// keep[j] = no box i < j of the k sorted boxes in sbox has iou(i,j) > thr, i.e.
+// max_{i<j} iou(i,j) <= thr (detection.py:190-202), order preserved.  Returns this thread's keep
+// flag (threads < k) and its rank among the kept ones in `pos`; `total` = number kept.  ssup[] must
+// be zero.  All threads must call it.
 template <int THREADS>
-__device__ bool fast_nms_keep(const float4* sbox, int* smax, int* s_wave_cnt, int k, float thr, int& pos, int& total) {
+__device__ bool fast_nms_keep(const float4* sbox, int* ssup, int* s_wave_cnt, int k, float thr, int& pos, int& total) {
   const int t = threadIdx.x;
   int sz = 64;                       // columns rounded up to a power of two; the rest of the
   while (sz < k) sz <<= 1;           // workgroup's threads split each column's rows
   const int G = THREADS / sz;
   const int j = t & (sz - 1), g = t / sz;
-  if (j < k) {
+  if (j < k && g < G) {
     const float4 bj = sbox[j];
-    float mx = 0.0f;   // +0.0f: the zeroed diagonal/lower triangle take part in reduce_max
-    for (int i = g; i < j; i += G) mx = fmaxf(mx, yp_iou(sbox[i], bj));
-    if (mx > 0.0f) atomicMax(&smax[j], __float_as_int(mx));   // iou >= 0: int order == float order
+    bool sup = false;
+    for (int i = g; i < j; i += G) sup = sup || yp_iou_gt(sbox[i], bj, thr);
+    if (sup) ssup[j] = 1;
   }
   __syncthreads();
   bool keep = false;
-  if (t < k) keep = __int_as_float(smax[t]) <= thr;
+  if (t < k) keep = ssup[t] == 0;
   pos = 0;
   if (t < YP_SORT_MAX) {
     const u64 ball = __ballot(keep);
@@ -391,8 +440,7 @@ __global__ __launch_bounds__(THREADS) void cc_nms_kernel(const NmsArgs p) {
   __shared__ SelectShared sh;
   __shared__ u64 stage[YP_STAGE_CAP];
   __shared__ float4 sbox[YP_SORT_MAX];
-  __shared__ int smax[YP_SORT_MAX];
-  __shared__ int s_anchor[YP_SORT_MAX];
+  __shared__ int ssup[YP_SORT_MAX];
   __shared__ int s_wave_cnt[YP_SORT_MAX / YP_WAVE];
   const int t = threadIdx.x;
   const int b = blockIdx.x;
@@ -401,133 +449,247 @@ __global__ __launch_bounds__(THREADS) void cc_nms_kernel(const NmsArgs p) {
   for (int i = t; i < p.parts; i += THREADS) part += counts[i];
   const int n = block_sum<THREADS>(part, sh.wtot);            // survivors of the confidence filter
   if (n == 0) {                                                // detection.py:81
-    finish_image<THREADS>(p, b, 0, s_anchor, 0);
+    finish_image<THREADS>(p, b, 0, 0);
     return;
   }
-  const PartSrc src{p.cand + (size_t)b * p.parts * p.cap_item, counts, p.parts, p.cap_item, 0};
+  const PartSrc src{p.cand + (size_t)b * p.parts * p.cap_item, counts, p.parts, p.cap_item, 0, 0, 0};
   const int k = select_topk_sorted<THREADS>(src, n, p.top_k, sh, stage);       // detection.py:186
   float4 mybox = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 cf[YP_MASK_DIM / 4];
+  int anchor = 0;
   if (t < YP_SORT_MAX) {
-    smax[t] = 0;
+    ssup[t] = 0;
     if (t < k) {                                                                        // L187, L79
-      const int a = min(yp_seg_key_anchor(sh.key[t]), p.A - 1);   // (clamp: never index out of bounds)
-      mybox = yp_decode(p.priors[a], p.off[(size_t)b * p.A + a]);
+      anchor = min(yp_seg_key_anchor(sh.key[t]), p.A - 1);   // (clamp: never index out of bounds)
+      const float4 pr = p.priors[anchor], of = p.off[(size_t)b * p.A + anchor];
+      load_coef(p, b, anchor, cf);   // same round trip; only the kept rows are stored
+      mybox = yp_decode(pr, of);
       sbox[t] = mybox;
     }
   }
   __syncthreads();
   int pos, total;
-  const bool keep = fast_nms_keep<THREADS>(sbox, smax, s_wave_cnt, k, p.nms_thresh, pos, total);
+  const bool keep = fast_nms_keep<THREADS>(sbox, ssup, s_wave_cnt, k, p.nms_thresh, pos, total);
   const int nk = min(total, p.max_dets);
   if (keep && pos < nk) {
     const u64 key = sh.key[t];
-    const int anchor = min(yp_seg_key_anchor(key), p.A - 1);
-    s_anchor[pos] = anchor;
-    emit_row(p, b, pos, yp_key_score(key), yp_seg_key_class(key), anchor, mybox);   // detection.py:204-207
+    emit_row(p, b, pos, yp_key_score(key), yp_seg_key_class(key), anchor, mybox, cf);   // detection.py:204-207
   }
-  __syncthreads();
-  finish_image<THREADS>(p, b, nk, s_anchor, n);
+  finish_image<THREADS>(p, b, nk, n);
 }
 
-// Per-class mode: one workgroup per (image, class) (detection.py:217-239).
+// ---- per-class mode -------------------------------------------------------------------------
+struct GroupShared {
+  u64 a[YP_GROUP_CAP];          // the group's keys as they arrive; later, per class, the top_k keys in descending order
+  u64 bk[YP_GROUP_CAP];         // keys bucketed by class; later the pooled NMS survivors (final-key format)
+  float4 box[YP_GROUP_CAP];     // decoded boxes, at the positions of `a`
+  unsigned char pcls[YP_GROUP_CAP];   // class of every bucket position
+  unsigned char psup[YP_GROUP_CAP];   // 1 = suppressed by a higher-ranked box of its class
+  SelectShared sh;
+  int cls_cnt[256], cls_off[256], cls_fill[256];
+  int ssup[YP_SORT_MAX];
+  int s_wave_cnt[YP_SORT_MAX / YP_WAVE];
+  int fill, npool;
+};
+
+// Top_k + Fast NMS of ONE class with the whole workgroup (any number of candidates): the path for
+// groups too large for the thread-per-candidate code.  Appends the survivors to pool[base...] and
+// returns their number.  All threads must call it.
 template <int THREADS>
-__global__ __launch_bounds__(THREADS) void class_nms_kernel(const NmsArgs p) {
-  __shared__ SelectShared sh;
-  __shared__ float4 sbox[YP_SORT_MAX];
-  __shared__ int smax[YP_SORT_MAX];
-  __shared__ int s_wave_cnt[YP_SORT_MAX / YP_WAVE];
+__device__ int class_nms_blockwide(const NmsArgs& p, int b, int cls, GroupShared& gs, u64* pool, int base) {
   const int t = threadIdx.x;
-  const int seg = blockIdx.x, b = blockIdx.y;
-  const size_t sidx = (size_t)b * p.nseg + seg;
-  // This class's candidates: one pass over the image's lists (a few tens of KB, shared by the
-  // image's C-1 workgroups through L2), keys of other classes skipped.
-  const PartSrc src{p.cand + (size_t)b * p.parts * p.cap_item, p.seg_count + (size_t)b * p.parts, p.parts, p.cap_item, seg + 1};
+  SelectShared& sh = gs.sh;
+  float4* sbox = gs.box;
+  const PartSrc src{p.cand + (size_t)b * p.parts * p.cap_item, p.seg_count + (size_t)b * p.parts, p.parts, p.cap_item, cls, 0, 0};
+  __syncthreads();
   if (t == 0) sh.fill = 0;
-  if (t < YP_SORT_MAX) { smax[t] = 0; sh.rank[t] = 0; }
+  if (t < YP_SORT_MAX) { gs.ssup[t] = 0; sh.rank[t] = 0; }
   __syncthreads();
   src.template for_each<THREADS>([&](u64 key) {
-    const int q = atomicAdd(&sh.fill, 1);
+    const int q = lds_append_slot(&sh.fill);
     if (q < YP_SORT_MAX) sh.tmp[q] = key;
   });
   __syncthreads();
   const int n = sh.fill;
-  if (n == 0) {
-    if (t == 0) p.pool_count[sidx] = 0;
-    return;
-  }
+  if (n == 0) return 0;
   int k;
   if (n <= YP_SORT_MAX) {
-    // Every candidate's box is fetched and decoded while its rank (= number of larger keys) is
-    // counted; key and box then go straight to their sorted position.
-    const bool have = t < n;
-    float4 pr = make_float4(0.f, 0.f, 0.f, 0.f), of = pr;
-    u64 mine = 0;
-    if (have) {
-      mine = sh.tmp[t];
-      const int a = min(yp_seg_key_anchor(mine), p.A - 1);
-      pr = p.priors[a];
-      of = p.off[(size_t)b * p.A + a];
-      int r = 0;
-      for (int i = 0; i < n; ++i) r += sh.tmp[i] > mine ? 1 : 0;
-      sh.key[r] = mine;
-      sbox[r] = yp_decode(pr, of);                                                      // detection.py:79
-    }
+    rank_sort_desc<THREADS>(sh, n);
     k = min(p.top_k, n);
-    __syncthreads();
   } else {
     __syncthreads();   // everybody has read sh.fill
     k = select_topk_sorted<THREADS>(src, n, p.top_k, sh, nullptr);                // detection.py:217
-    if (t < YP_SORT_MAX) {
-      if (t < k) {                                                                      // detection.py:219
-        const int a = min(yp_seg_key_anchor(sh.key[t]), p.A - 1);   // (clamp: never index out of bounds)
-        sbox[t] = yp_decode(p.priors[a], p.off[(size_t)b * p.A + a]);
-      }
-    }
-    __syncthreads();
   }
+  if (t < k) {                                                                          // detection.py:219
+    const int a = min(yp_seg_key_anchor(sh.key[t]), p.A - 1);   // (clamp: never index out of bounds)
+    sbox[t] = yp_decode(p.priors[a], p.off[(size_t)b * p.A + a]);
+  }
+  __syncthreads();
   int pos, total;
-  const bool keep = fast_nms_keep<THREADS>(sbox, smax, s_wave_cnt, k, p.nms_thresh, pos, total);
-  // class-major pool of survivors for the cross-class top-N               (detection.py:234-239)
-  if (keep) {
+  const bool keep = fast_nms_keep<THREADS>(sbox, gs.ssup, gs.s_wave_cnt, k, p.nms_thresh, pos, total);
+  if (keep) {                                                                           // detection.py:234-239
     const u64 key = sh.key[t];
-    p.pool[sidx * p.top_k + pos] = yp_fin_key(yp_key_score(key), yp_seg_key_anchor(key), seg + 1);
+    pool[base + pos] = yp_fin_key(yp_key_score(key), yp_seg_key_anchor(key), cls);
   }
-  if (t == 0) p.pool_count[sidx] = total;
+  return total;
 }
 
-// Per-class mode only: cross-class top max_dets over the pooled survivors (detection.py:242-248).
+// Workgroup (g, b): the classes c of image b with (c-1) % ngroups == g (detection.py:217-239).
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void group_nms_kernel(const NmsArgs p) {
+  static_assert(THREADS * YP_GROUP_KPT >= YP_GROUP_CAP, "every candidate needs a thread slot");
+  __shared__ GroupShared gs;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int g = blockIdx.x, b = blockIdx.y;
+  u64* const pool = p.pool + ((size_t)b * p.ngroups + g) * p.gcap;
+  // 1. one pass over the image's lists (a few tens of KB, shared by the image's workgroups through
+  //    L2): this group's keys into LDS, class histogram on the way
+  if (t < 256) { gs.cls_cnt[t] = 0; gs.cls_fill[t] = 0; }
+  if (t == 0) { gs.fill = 0; gs.npool = 0; }
+  __syncthreads();
+  const PartSrc src{p.cand + (size_t)b * p.parts * p.cap_item, p.seg_count + (size_t)b * p.parts, p.parts, p.cap_item, 0, p.ngroups, g};
+  src.template for_each<THREADS>([&](u64 key) {
+    const int q = lds_append_slot(&gs.fill);
+    if (q < YP_GROUP_CAP) gs.a[q] = key;
+    atomicAdd(&gs.cls_cnt[yp_seg_key_class(key)], 1);
+  });
+  __syncthreads();
+  const int m = gs.fill;
+  if (m == 0) {
+    if (t == 0) p.pool_count[(size_t)b * p.ngroups + g] = 0;
+    return;
+  }
+  if (m > YP_GROUP_CAP) {
+    // too many for LDS: class by class, each with the whole workgroup
+    int base = 0;
+    for (int c = g + 1; c <= p.nseg; c += p.ngroups) base += class_nms_blockwide<THREADS>(p, b, c, gs, pool, base);
+    if (t == 0) p.pool_count[(size_t)b * p.ngroups + g] = base;
+    return;
+  }
+  // 2. class offsets (exclusive prefix over the 256 possible class ids)
+  int cv = 0, incl = 0;
+  if (t < 256) {
+    cv = gs.cls_cnt[t];
+    incl = cv;
+    for (int o = 1; o < 64; o <<= 1) {
+      const int u = __shfl_up(incl, o);
+      if (lane >= o) incl += u;
+    }
+    if (lane == 63) gs.sh.wtot[wave] = incl;
+  }
+  __syncthreads();
+  if (t < 256) {
+    int base = 0;
+    for (int w = 0; w < wave; ++w) base += gs.sh.wtot[w];
+    gs.cls_off[t] = base + incl - cv;
+  }
+  __syncthreads();
+  // 3. bucket by class (the order inside a bucket is arbitrary; the ranks below do not depend on it)
+  for (int i = t; i < m; i += THREADS) {
+    const u64 key = gs.a[i];
+    const int c = yp_seg_key_class(key);
+    const int pos = gs.cls_off[c] + atomicAdd(&gs.cls_fill[c], 1);
+    gs.bk[pos] = key;
+    gs.pcls[pos] = (unsigned char)c;
+    gs.psup[pos] = 0;
+  }
+  __syncthreads();
+  // 4. per candidate: fetch prior + offsets (one round trip for the whole group), rank inside the
+  //    class (= number of larger keys: tf.math.top_k order, detection.py:217), decode, and move key
+  //    and box to the sorted position if the rank is inside top_k (detection.py:219)
+  {
+    u64 key[YP_GROUP_KPT];
+    float4 pr[YP_GROUP_KPT], of[YP_GROUP_KPT];
+#pragma unroll
+    for (int u = 0; u < YP_GROUP_KPT; ++u) {
+      const int i = t + u * THREADS;
+      key[u] = gs.bk[min(i, m - 1)];
+      const int a = min(yp_seg_key_anchor(key[u]), p.A - 1);
+      pr[u] = p.priors[a];
+      of[u] = p.off[(size_t)b * p.A + a];
+    }
+#pragma unroll
+    for (int u = 0; u < YP_GROUP_KPT; ++u) {
+      const int i = t + u * THREADS;
+      if (i < m) {
+        const int c = yp_seg_key_class(key[u]);
+        const int lo = gs.cls_off[c], cnt = gs.cls_cnt[c];
+        int r = 0;
+        for (int q = 0; q < cnt; ++q) r += gs.bk[lo + q] > key[u] ? 1 : 0;
+        if (r < p.top_k) {
+          gs.a[lo + r] = key[u];
+          gs.box[lo + r] = yp_decode(pr[u], of[u]);                                     // detection.py:79
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // 5. Fast NMS inside every class: a candidate survives unless a higher-ranked box of its class
+  //    overlaps it by more than the threshold (detection.py:221-234; every candidate has p > conf)
+  //    Four lanes share a candidate's rows: the loop is a chain of LDS round trips, so its length,
+  //    not its instruction count, is what costs.
+  for (int w = t; w < 4 * m; w += THREADS) {
+    const int i = w >> 2, sub = w & 3;
+    const int c = gs.pcls[i];
+    const int lo = gs.cls_off[c];
+    const int r = i - lo;
+    if (r < min(gs.cls_cnt[c], p.top_k)) {
+      const float4 bj = gs.box[i];
+      bool sup = false;
+      for (int q = sub; q < r && !sup; q += 4) sup = yp_iou_gt(gs.box[lo + q], bj, p.nms_thresh);
+      if (sup) gs.psup[i] = 1;
+    }
+  }
+  __syncthreads();
+  for (int i = t; i < m; i += THREADS) {
+    const int c = gs.pcls[i];
+    if (gs.psup[i] == 0 && i - gs.cls_off[c] < min(gs.cls_cnt[c], p.top_k)) {
+      const u64 key = gs.a[i];
+      gs.bk[lds_append_slot(&gs.npool)] = yp_fin_key(yp_key_score(key), yp_seg_key_anchor(key), c);
+    }
+  }
+  __syncthreads();
+  // 6. the group's survivors, dense, for the cross-class selection (detection.py:234-239)
+  const int np = gs.npool;
+  for (int i = t; i < np; i += THREADS) pool[i] = gs.bk[i];
+  if (t == 0) p.pool_count[(size_t)b * p.ngroups + g] = np;
+}
+
+// Per-class mode: cross-class top max_dets over the pooled survivors (detection.py:242-248).
 template <int THREADS>
 __global__ __launch_bounds__(THREADS) void final_select_kernel(const NmsArgs p) {
   __shared__ SelectShared sh;
   __shared__ u64 stage[YP_STAGE_CAP];
-  __shared__ int s_anchor[YP_SORT_MAX];
+  __shared__ int start[32];
   const int t = threadIdx.x;
   const int b = blockIdx.x;
-  const int32_t* counts = p.pool_count + (size_t)b * p.nseg;
+  if (t == 0) {
+    int acc = 0;
+    for (int g = 0; g < p.ngroups; ++g) { start[g] = acc; acc += p.pool_count[(size_t)b * p.ngroups + g]; }
+    start[p.ngroups] = acc;
+  }
   int part = 0;
-  for (int i = t; i < p.nseg; i += THREADS) part += counts[i];
-  const int n = block_sum<THREADS>(part, sh.wtot);
-  part = 0;
   for (int i = t; i < p.parts; i += THREADS) part += p.seg_surv[(size_t)b * p.parts + i];
-  const int survivors = block_sum<THREADS>(part, sh.wtot);
+  const int survivors = block_sum<THREADS>(part, sh.wtot);   // (its barriers also publish start[])
+  const int n = start[p.ngroups];
   int k = 0;
   if (n > 0) {
-    const SlotSrc src{p.pool + (size_t)b * p.nseg * p.top_k, counts, p.nseg, p.top_k};
+    const PoolSrc src{p.pool + (size_t)b * p.ngroups * p.gcap, start, p.ngroups, p.gcap};
     k = select_topk_sorted<THREADS>(src, n, min(p.max_dets, YP_SORT_MAX), sh, stage);
     if (t < k) {
       const u64 key = sh.key[t];
       const int anchor = min(yp_fin_key_anchor(key), p.A - 1);
-      s_anchor[t] = anchor;
-      emit_row(p, b, t, yp_key_score(key), yp_fin_key_class(key), anchor,
-               yp_decode(p.priors[anchor], p.off[(size_t)b * p.A + anchor]));
+      const float4 pr = p.priors[anchor], of = p.off[(size_t)b * p.A + anchor];
+      float4 cf[YP_MASK_DIM / 4];
+      load_coef(p, b, anchor, cf);
+      emit_row(p, b, t, yp_key_score(key), yp_fin_key_class(key), anchor, yp_decode(pr, of), cf);
     }
-    __syncthreads();
   }
-  finish_image<THREADS>(p, b, k, s_anchor, survivors);
+  finish_image<THREADS>(p, b, k, survivors);
 }
 
-static NmsArgs make_args(const yp_handle* h, int batch, const float* pred_offset, const float* priors, const float* pred_mask_coef, float* det_boxes, float* det_classes,
-                         float* det_scores, int32_t* num_det, int32_t* kept_idx) {
+static NmsArgs make_args(const yp_handle* h, int batch, const float* pred_offset, const float* priors, const float* pred_mask_coef,
+                         float* det_boxes, float* det_classes, float* det_scores, int32_t* num_det, int32_t* kept_idx) {
   NmsArgs a;
   a.cand = h->s.cand; a.seg_count = h->s.seg_count; a.seg_surv = h->s.seg_surv; a.stat_surv = h->s.stat_surv;
   a.off = reinterpret_cast<const float4*>(pred_offset); a.priors = reinterpret_cast<const float4*>(priors);
@@ -542,6 +704,7 @@ static NmsArgs make_args(const yp_handle* h, int batch, const float* pred_offset
   a.proto_h = (float)h->cfg.proto_h; a.proto_w = (float)h->cfg.proto_w;
   a.use_crop = h->cfg.use_cropped_mask;
   yp_plan_items(h, batch, &a.parts, &a.cap_item);
+  yp_plan_groups(h, &a.ngroups, &a.gcap);
   return a;
 }
 
@@ -553,7 +716,7 @@ hipError_t yp_launch_segment_nms(const yp_handle* h, int batch, const float* pre
   if (h->cfg.nms_mode == YP_NMS_CROSS_CLASS)
     hipLaunchKernelGGL((cc_nms_kernel<1024>), dim3(batch), dim3(1024), 0, st, a);
   else
-    hipLaunchKernelGGL((class_nms_kernel<256>), dim3(h->nseg, batch), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((group_nms_kernel<YP_GROUP_THREADS>), dim3(a.ngroups, batch), dim3(YP_GROUP_THREADS), 0, st, a);
   return hipGetLastError();
 }
 
