@@ -26,7 +26,7 @@ struct MaskArgs {
 };
 
 #define YP_MASK_BLOCK 256
-#define YP_MASK_ROW4 9   // float4 per pixel row in LDS: 8 of data + 1 of padding (144-byte stride)
+#define YP_MASK_ROW4 3   // float4 per pixel row in LDS: 2 of data + 1 of padding (48-byte stride: conflict-free b128 reads)
 
 // One workgroup = 256 consecutive proto pixels of one image; a lane owns one pixel.
 //   1. the block's 256 x 32 prototype values (32 KiB, contiguous in HBM) are fetched with fully
@@ -50,9 +50,14 @@ __global__ __launch_bounds__(YP_MASK_BLOCK) void mask_assemble_kernel(const Mask
   const int npx = min(YP_MASK_BLOCK, p.P - base_pix);
   const int pix = base_pix + t;
   const bool live = t < npx;
-  const int N = min(p.num_det[b], p.sel_rows);
+  const int N = __builtin_amdgcn_readfirstlane(min(p.num_det[b], p.sel_rows));   // wave-uniform
 
+  float pr[YP_MASK_DIM];
   {
+    // Thread t's float4 number i of the block's 32 KiB is quad (t & 7) of pixel i*32 + (t >> 3).  The
+    // transpose goes through LDS two quads at a time (four passes over a 12 KiB buffer instead of one
+    // pass over 36 KiB): LDS is what limits residency here, and with it the waves that hide each
+    // other's latencies.
     const nat4* src = reinterpret_cast<const nat4*>(p.proto + ((size_t)b * p.P + base_pix) * YP_MASK_DIM);
     nat4 x[YP_MASK_DIM / 4];
 #pragma unroll
@@ -61,35 +66,41 @@ __global__ __launch_bounds__(YP_MASK_BLOCK) void mask_assemble_kernel(const Mask
       x[i] = __builtin_nontemporal_load(src + min(idx, npx * (YP_MASK_DIM / 4) - 1));
     }
 #pragma unroll
-    for (int i = 0; i < YP_MASK_DIM / 4; ++i) {
-      const int idx = i * YP_MASK_BLOCK + t;
-      sproto[(idx >> 3) * YP_MASK_ROW4 + (idx & 7)] = make_float4(x[i].x, x[i].y, x[i].z, x[i].w);
-    }
-  }
-  __syncthreads();
-  float pr[YP_MASK_DIM];
+    for (int q = 0; q < YP_MASK_DIM / 8; ++q) {
+      if (q > 0) __syncthreads();            // the previous pass has been read
+      if (((t & 7) >> 1) == q) {
 #pragma unroll
-  for (int v = 0; v < YP_MASK_DIM / 4; ++v) {
-    const float4 x = sproto[t * YP_MASK_ROW4 + v];
-    pr[4 * v + 0] = x.x; pr[4 * v + 1] = x.y; pr[4 * v + 2] = x.z; pr[4 * v + 3] = x.w;
+        for (int i = 0; i < YP_MASK_DIM / 4; ++i)
+          sproto[(i * (YP_MASK_BLOCK / 8) + (t >> 3)) * YP_MASK_ROW4 + (t & 1)] = make_float4(x[i].x, x[i].y, x[i].z, x[i].w);
+      }
+      __syncthreads();
+      const float4 lo = sproto[t * YP_MASK_ROW4 + 0], hi = sproto[t * YP_MASK_ROW4 + 1];
+      pr[8 * q + 0] = lo.x; pr[8 * q + 1] = lo.y; pr[8 * q + 2] = lo.z; pr[8 * q + 3] = lo.w;
+      pr[8 * q + 4] = hi.x; pr[8 * q + 5] = hi.y; pr[8 * q + 6] = hi.z; pr[8 * q + 7] = hi.w;
+    }
   }
   const int r = pix / p.pw;
   const float frow = live ? (float)r : -1.0f;                  // tf.range(..., dtype=float32), utils/utils.py:119-120
   const float fcol = live ? (float)(pix - r * p.pw) : -1.0f;
 
-  float* optr = p.masks + ((size_t)b * p.max_dets) * p.P + pix;
-  uint8_t* bptr = p.bitmaps ? p.bitmaps + ((size_t)b * p.max_dets) * p.P + pix : nullptr;
+  // Row addresses are a wave-uniform base (SGPRs, advanced by scalar adds) plus the lane's constant
+  // offset: a row of zeros then costs one store and no vector arithmetic at all - the kernel is bound
+  // by instruction issue as much as by HBM.
+  float* orow = p.masks + ((size_t)b * p.max_dets) * p.P + base_pix;
+  uint8_t* brow = p.bitmaps ? p.bitmaps + ((size_t)b * p.max_dets) * p.P + base_pix : nullptr;
   typedef const __attribute__((address_space(4))) float cfloat;
   cfloat* const crop_c = (cfloat*)(p.crop + (size_t)b * p.sel_rows);
   cfloat* const coef_c = (cfloat*)(p.coef + (size_t)b * p.sel_rows * YP_MASK_DIM);
 
   // Which detections can touch this wave's 64 pixels at all?  Lane l tests detection g*64+l against
   // a bounding range of the wave's pixels (a superset test: the per-pixel compares below decide the
-  // values); the ballots give a bit per detection.  Rows of all other detections are plain zeros
-  // and cost a handful of instructions each - the kernel is otherwise bound by instruction issue,
-  // not by HBM.
+  // values); the ballots give a bit per detection.  Rows of all other detections are plain zeros.
+  // The kernel is bound by instruction issue as much as by HBM, so everything wave-uniform is kept
+  // in SGPRs on purpose (readfirstlane where the compiler cannot prove it): the bit test is scalar,
+  // and a row's address is a scalar base plus the lane's constant byte offset - a row of zeros
+  // costs one store and no vector arithmetic.
   const int lane = t & 63;
-  const int w0 = base_pix + (t & ~63), w1 = min(w0 + 63, p.P - 1);
+  const int w0 = base_pix + __builtin_amdgcn_readfirstlane(t >> 6) * 64, w1 = min(w0 + 63, p.P - 1);
   u64 rel[YP_SORT_MAX / 64] = {0ull, 0ull, 0ull, 0ull};
   if (w0 < p.P) {
     const int r0 = w0 / p.pw, r1 = w1 / p.pw;
@@ -102,16 +113,40 @@ __global__ __launch_bounds__(YP_MASK_BLOCK) void mask_assemble_kernel(const Mask
         const int n = g * 64 + lane;
         const float4 cb = p.crop[(size_t)b * p.sel_rows + min(n, N - 1)];
         const bool hit = (n < N) && (fc1 >= cb.x) && (fc0 < cb.y) && (fr1 >= cb.z) && (fr0 < cb.w);
-        rel[g] = __ballot(hit);
+        const u64 m = __ballot(hit);
+        rel[g] = ((u64)(uint32_t)__builtin_amdgcn_readfirstlane((int)(m >> 32)) << 32) |
+                 (u64)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)m);
       }
     }
   }
-
-  for (int n = 0; n < N; ++n, optr += p.P, bptr += (bptr ? p.P : 0)) {
-    const int g = n >> 6;
-    const u64 word = g == 0 ? rel[0] : (g == 1 ? rel[1] : (g == 2 ? rel[2] : rel[3]));
-    float v = 0.0f;
-    if ((word >> (n & 63)) & 1ull) {   // wave-uniform
+  // The CU's scalar unit is shared by all its waves, and a loop over every detection with a test and
+  // a branch per row is bound by it (measured: ~36 of 62 us with no memory traffic at all).  So:
+  //   pass Z  every row gets zeros: one store + one vector add per row, nothing scalar but the loop
+  //   pass R  only the rows whose bit is set (found with ctz) are computed and stored again; stores
+  //           of one wave to one address stay in order
+  const uint32_t voff = (uint32_t)t * 4u;
+  const uint32_t rstride = (uint32_t)p.P * 4u;
+  const bool plain = !NT_STORE && brow == nullptr;
+  if (live) {
+    if (plain) {
+      uint32_t vo = voff;
+      const float zero = 0.0f;
+#pragma unroll 4
+      for (int n = 0; n < N; ++n, vo += rstride)
+        asm volatile("global_store_dword %0, %1, %2" ::"v"(vo), "v"(zero), "s"(orow) : "memory");
+    } else {
+      for (int n = 0; n < N; ++n) {
+        if (NT_STORE) __builtin_nontemporal_store(0.0f, orow + (size_t)n * p.P + t); else orow[(size_t)n * p.P + t] = 0.0f;
+        if (brow) brow[(size_t)n * p.P + t] = 0.0f > p.mask_threshold ? 1 : 0;               // train.py:497
+      }
+    }
+  }
+#pragma unroll
+  for (int g = 0; g < YP_SORT_MAX / 64; ++g) {
+    u64 w = g * 64 < N ? rel[g] : 0ull;        // wave-uniform
+    while (w != 0ull) {
+      const int n = g * 64 + __builtin_ctzll(w);
+      w &= w - 1ull;
       // Crop edges and coefficients of detection n are wave-uniform and were written by the previous
       // kernel: read them through the constant address space so they arrive by scalar loads (SGPRs,
       // scalar cache) and never wait on this wave's own outstanding vector stores.
@@ -120,17 +155,21 @@ __global__ __launch_bounds__(YP_MASK_BLOCK) void mask_assemble_kernel(const Mask
       cfloat* const cf = coef_c + n * YP_MASK_DIM;
       // mask_left & mask_right & mask_bottom & mask_top, float compares (utils/utils.py:125-130)
       const bool in = live && (fcol >= cb.x) && (fcol < cb.y) && (frow >= cb.z) && (frow < cb.w);
-      if (__ballot(in)) {
-        float acc = 0.0f;
+      if (__ballot(in) == 0ull) continue;      // the superset test let it through: the zeros stand
+      float acc = 0.0f;
 #pragma unroll
-        for (int k = 0; k < YP_MASK_DIM; ++k) acc = __builtin_fmaf(pr[k], cf[k], acc);     // detection.py:89
-        const float sg = yp_sigmoid(acc);                                                  // detection.py:90
-        v = yp_clip(in ? sg : 0.0f, 0.0f, 1.0f);                                            // utils.py:133, L105
+      for (int k = 0; k < YP_MASK_DIM; ++k) acc = __builtin_fmaf(pr[k], cf[k], acc);       // detection.py:89
+      const float sg = yp_sigmoid(acc);                                                    // detection.py:90
+      const float v = yp_clip(in ? sg : 0.0f, 0.0f, 1.0f);                                  // utils.py:133, L105
+      if (live) {
+        if (plain) {
+          const uint32_t vo = voff + (uint32_t)n * rstride;
+          asm volatile("global_store_dword %0, %1, %2" ::"v"(vo), "v"(v), "s"(orow) : "memory");
+        } else {
+          if (NT_STORE) __builtin_nontemporal_store(v, orow + (size_t)n * p.P + t); else orow[(size_t)n * p.P + t] = v;
+          if (brow) brow[(size_t)n * p.P + t] = v > p.mask_threshold ? 1 : 0;                // train.py:497
+        }
       }
-    }
-    if (live) {
-      if (NT_STORE) __builtin_nontemporal_store(v, optr); else *optr = v;
-      if (bptr) *bptr = v > p.mask_threshold ? 1 : 0;                                      // train.py:497
     }
   }
   float* const out_img = p.masks + (size_t)b * p.max_dets * p.P;
