@@ -126,6 +126,9 @@ extern "C" int yp_create(const yp_config* cfg, yp_handle** out) {
     return fail(YP_EHIP, "hipMemset of the counters failed");
   }
   (void)hipDeviceSynchronize();
+#ifdef YP_STAMPS
+  (void)hipMalloc(&h->dbg, 3 * 4096 * 16 * 8); (void)hipMemset(h->dbg, 0, 3 * 4096 * 16 * 8);
+#endif
   *out = h;
   g_err[0] = 0;
   return YP_OK;
@@ -211,5 +214,14 @@ extern "C" int yp_profile_read(yp_handle* h, float* ms_out) {
   for (int i = 0; i < YP_NUM_KERNELS; ++i) YP_HIP(hipEventElapsedTime(&ms_out[i], h->ev[i], h->ev[i + 1]));
   return YP_OK;
 }
+
+#ifdef YP_STAMPS
+// diagnostic build only: copies the [3][4096][16] stamp table to the host
+extern "C" int yp_debug_stamps(yp_handle* h, unsigned long long* host_out) {
+  if (!h || !host_out) return YP_EINVAL;
+  (void)hipDeviceSynchronize();
+  return hipMemcpy(host_out, h->dbg, 3 * 4096 * 16 * 8, hipMemcpyDeviceToHost) == hipSuccess ? YP_OK : YP_EHIP;
+}
+#endif
 
 extern "C" int64_t yp_scratch_bytes(const yp_handle* h) { return h ? h->scratch_bytes : 0; }

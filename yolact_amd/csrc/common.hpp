@@ -133,6 +133,9 @@ struct yp_handle {
   int sf_bufb;          // score_filter: bytes of a wave's LDS tile buffer
   int sf_waves_per_cu;  // score_filter: single-wave workgroups resident per CU
   int keys_per_anchor;  // most keys one anchor can emit: 1 (cross-class) or min(C-1, floor(1/conf)+1)
+#ifdef YP_STAMPS
+  void* dbg;            // diagnostic build only: cycle stamps
+#endif
   void* scratch_base;
   int64_t scratch_bytes;
   yp_scratch s;

@@ -48,7 +48,17 @@ struct NmsArgs {
   long long cap_item;
   float nms_thresh, img_h, img_w, proto_h, proto_w;
   int use_crop;
+#ifdef YP_STAMPS
+  unsigned long long* dbg;   // diagnostic build: [kernel 0..2][block][16] cycle stamps of thread 0
+#endif
 };
+#ifdef YP_STAMPS
+#define STAMP_INIT(kern, blk) unsigned long long* const dbg_ = p.dbg + ((size_t)(kern) * 4096 + (blk)) * 16; if (threadIdx.x == 0) dbg_[15] = 1
+#define STAMP(i) do { if (threadIdx.x == 0) dbg_[i] = (unsigned long long)clock64(); } while (0)
+#else
+#define STAMP_INIT(kern, blk)
+#define STAMP(i)
+#endif
 
 struct SelectShared {
   u64 key[YP_SORT_MAX];    // result: selected keys, sorted descending
@@ -120,22 +130,60 @@ struct PoolSrc {   // ngroups lists of gcap slots; list g holds its keys at [0, 
   int ngroups, gcap;
   template <int THREADS, class F>
   __device__ __forceinline__ void for_each(F f) const {
-    const int n = start[ngroups];
-    for (int i0 = threadIdx.x; i0 < n; i0 += THREADS * YP_SRC_UNROLL) {
-      u64 k[YP_SRC_UNROLL];
+    int sft = 0;     // 1 << sft threads share a list
+    while ((2 << sft) * ngroups <= THREADS && sft < 6) ++sft;
+    const int lpp = 1 << sft;
+    for (int s = threadIdx.x; s < (ngroups << sft); s += THREADS) {
+      const int g = s >> sft, q = s & (lpp - 1);
+      const int n = start[g + 1] - start[g];
+      const u64* l = base + (size_t)g * gcap;
+      for (int i0 = q; i0 < n; i0 += lpp * YP_SRC_UNROLL) {
+        u64 k[YP_SRC_UNROLL];
 #pragma unroll
-      for (int u = 0; u < YP_SRC_UNROLL; ++u) {
-        const int i = min(i0 + u * THREADS, n - 1);
-        int g = 0;
-        while (start[g + 1] <= i) ++g;      // <= 16 groups
-        k[u] = base[(size_t)g * gcap + (i - start[g])];
+        for (int u = 0; u < YP_SRC_UNROLL; ++u) k[u] = l[min(i0 + u * lpp, n - 1)];
+#pragma unroll
+        for (int u = 0; u < YP_SRC_UNROLL; ++u)
+          if (i0 + u * lpp < n) f(k[u]);
       }
-#pragma unroll
-      for (int u = 0; u < YP_SRC_UNROLL; ++u)
-        if (i0 + u * THREADS < n) f(k[u]);
     }
   }
 };
+
+// ---- wave-wide scans and reductions on DPP (one VALU op per step; a __shfl is an LDS round trip) ----
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_id(int identity, int v) { return __builtin_amdgcn_update_dpp(identity, v, CTRL, ROW_MASK, 0xF, false); }
+// inclusive prefix sum over the 64 lanes: Hillis-Steele inside each row of 16 (row_shr 1,2,4,8),
+// then row 0 -> 1 and 2 -> 3 (row_bcast:15), then rows 0-1 -> 2-3 (row_bcast:31)
+__device__ __forceinline__ int wave_incl_scan(int v) {
+  v += dpp_id<0x111, 0xF>(0, v);
+  v += dpp_id<0x112, 0xF>(0, v);
+  v += dpp_id<0x114, 0xF>(0, v);
+  v += dpp_id<0x118, 0xF>(0, v);
+  v += dpp_id<0x142, 0xA>(0, v);
+  v += dpp_id<0x143, 0xC>(0, v);
+  return v;
+}
+__device__ __forceinline__ int wave_sum(int v) { return __builtin_amdgcn_readlane(wave_incl_scan(v), 63); }
+__device__ __forceinline__ uint32_t wave_or(uint32_t x) {
+  int v = (int)x;
+  v |= dpp_id<0x111, 0xF>(0, v);
+  v |= dpp_id<0x112, 0xF>(0, v);
+  v |= dpp_id<0x114, 0xF>(0, v);
+  v |= dpp_id<0x118, 0xF>(0, v);
+  v |= dpp_id<0x142, 0xA>(0, v);
+  v |= dpp_id<0x143, 0xC>(0, v);
+  return (uint32_t)__builtin_amdgcn_readlane(v, 63);
+}
+__device__ __forceinline__ uint32_t wave_and(uint32_t x) {
+  int v = (int)x;
+  v &= dpp_id<0x111, 0xF>(-1, v);
+  v &= dpp_id<0x112, 0xF>(-1, v);
+  v &= dpp_id<0x114, 0xF>(-1, v);
+  v &= dpp_id<0x118, 0xF>(-1, v);
+  v &= dpp_id<0x142, 0xA>(-1, v);
+  v &= dpp_id<0x143, 0xC>(-1, v);
+  return (uint32_t)__builtin_amdgcn_readlane(v, 63);
+}
 
 // Slot in an LDS list for every calling lane: one LDS atomic per wave instead of one per lane (lanes
 // adding to one address are served one after the other).  May be called under divergence: the lanes
@@ -152,7 +200,7 @@ __device__ __forceinline__ int lds_append_slot(int* counter) {
 
 template <int THREADS>
 __device__ int block_sum(int v, int* wtot) {   // wtot: >= THREADS/64 ints of LDS
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+  v = wave_sum(v);
   __syncthreads();
   if ((threadIdx.x & 63) == 0) wtot[threadIdx.x >> 6] = v;
   __syncthreads();
@@ -179,15 +227,19 @@ __device__ void hist_pass(const Src& src, u64 mask, u64 prefix, int shift, u64 d
   int tsum = 0;
 #pragma unroll
   for (int i = 0; i < BPT; ++i) { loc[i] = sh.hist[t * BPT + i]; tsum += loc[i]; }
-  int incl = tsum;   // -> sum over lanes >= lane of this wave
-  for (int o = 1; o < 64; o <<= 1) {
-    const int v = __shfl_down(incl, o);
-    if (lane + o < 64) incl += v;
-  }
-  if (lane == 0) sh.wtot[wave] = incl;
+  const int incl = wave_incl_scan(tsum);                       // sum over lanes <= lane of this wave
+  const int wtotal = __builtin_amdgcn_readlane(incl, 63);
+  if (lane == 0) sh.wtot[wave] = wtotal;
   __syncthreads();
-  int above = incl - tsum;   // keys in higher bins
-  for (int w = wave + 1; w < THREADS / 64; ++w) above += sh.wtot[w];
+  int above = wtotal - incl;   // keys in higher bins: the lanes above in this wave, then the waves above
+  {
+    const int4* w4 = reinterpret_cast<const int4*>(sh.wtot);
+#pragma unroll
+    for (int q = 0; q < THREADS / 256; ++q) {
+      const int4 x = w4[q];
+      above += (4 * q + 0 > wave ? x.x : 0) + (4 * q + 1 > wave ? x.y : 0) + (4 * q + 2 > wave ? x.z : 0) + (4 * q + 3 > wave ? x.w : 0);
+    }
+  }
 #pragma unroll
   for (int i = BPT - 1; i >= 0; --i) {
     if (above < need && need <= above + loc[i]) { sh.sel = t * BPT + i; sh.need = need - above; sh.cnt = loc[i]; }
@@ -230,6 +282,7 @@ __device__ void rank_sort_desc(SelectShared& sh, int m) {
   if (j < m) {
     mine = sh.tmp[j];
     int c = 0;
+#pragma unroll 8
     for (int i = g; i < m; i += G) c += sh.tmp[i] > mine ? 1 : 0;
     if (G == 1) sh.rank[j] = c;
     else if (c) atomicAdd(&sh.rank[j], c);
@@ -242,15 +295,6 @@ __device__ void rank_sort_desc(SelectShared& sh, int m) {
   __syncthreads();
 }
 
-__device__ __forceinline__ u64 wave_min_u64(u64 v) {
-  for (int o = 32; o > 0; o >>= 1) { const u64 w = __shfl_xor(v, o); v = w < v ? w : v; }
-  return v;
-}
-__device__ __forceinline__ u64 wave_max_u64(u64 v) {
-  for (int o = 32; o > 0; o >>= 1) { const u64 w = __shfl_xor(v, o); v = w > v ? w : v; }
-  return v;
-}
-
 // Leaves the k = min(want, n) largest keys of src in sh.key[0..k), descending; returns k.
 // All threads of the workgroup must call it.  Keys are unique and non-zero.  `stage` is an optional
 // LDS buffer of YP_STAGE_CAP keys.
@@ -260,7 +304,12 @@ __device__ __forceinline__ u64 wave_max_u64(u64 v) {
 //   the bin itself are <= 256 (the normal case: the bins are narrow) they are rank-sorted and the
 //   first k are the answer.  Otherwise a full MSB-first radix select runs.
 template <int THREADS, class Src>
-__device__ int select_topk_sorted(const Src& src, int n, int want, SelectShared& sh, u64* stage) {
+__device__ int select_topk_sorted(const Src& src, int n, int want, SelectShared& sh, u64* stage, unsigned long long* dbg_ = nullptr) {
+#ifdef YP_STAMPS
+#define SSTAMP(i) do { if (dbg_ && threadIdx.x == 0) dbg_[i] = (unsigned long long)clock64(); } while (0)
+#else
+#define SSTAMP(i)
+#endif
   const int t = threadIdx.x;
   const int k = min(want, n);
   if (t == 0) { sh.fill = 0; sh.lo = ~0ull; sh.hi = 0ull; }
@@ -275,18 +324,19 @@ __device__ int select_topk_sorted(const Src& src, int n, int want, SelectShared&
     m = n;
   } else {
     const bool staged = stage != nullptr && n <= YP_STAGE_CAP;
-    u64 lo = ~0ull, hi = 0ull;
+    u64 lo = ~0ull, hi = 0ull;   // AND / OR of the keys: they differ exactly in the bits of lo ^ hi
     src.template for_each<THREADS>([&](u64 key) {
-      lo = key < lo ? key : lo;
-      hi = key > hi ? key : hi;
+      lo &= key;
+      hi |= key;
       if (staged) {
         const int q = lds_append_slot(&sh.fill);
         if (q < YP_STAGE_CAP) stage[q] = key;
       }
     });
-    lo = wave_min_u64(lo);
-    hi = wave_max_u64(hi);
-    if ((t & 63) == 0) { atomicMin(&sh.lo, lo); atomicMax(&sh.hi, hi); }
+    SSTAMP(8);
+    lo = ((u64)wave_and((uint32_t)(lo >> 32)) << 32) | wave_and((uint32_t)lo);
+    hi = ((u64)wave_or((uint32_t)(hi >> 32)) << 32) | wave_or((uint32_t)hi);
+    if ((t & 63) == 0) { atomicAnd(&sh.lo, lo); atomicOr(&sh.hi, hi); }
     __syncthreads();
     if (t == 0) sh.fill = 0;
     const u64 diff = sh.lo ^ sh.hi;                         // != 0: more than one distinct key
@@ -296,6 +346,7 @@ __device__ int select_topk_sorted(const Src& src, int n, int want, SelectShared&
     const ListSrc ls{stage, n};
     if (staged) hist_pass<THREADS>(ls, 0ull, 0ull, shift, dmask, k, sh);   // bits above `top` are common
     else hist_pass<THREADS>(src, 0ull, 0ull, shift, dmask, k, sh);
+    SSTAMP(9);
     const int sel = sh.sel;
     const int superset = (k - sh.need) + sh.cnt;            // keys in bins >= sel
     if (superset <= YP_SORT_MAX) {
@@ -322,7 +373,9 @@ __device__ int select_topk_sorted(const Src& src, int n, int want, SelectShared&
     }
   }
   __syncthreads();
+  SSTAMP(10);
   rank_sort_desc<THREADS>(sh, m);
+  SSTAMP(11);
   return k;
 }
 
@@ -344,6 +397,15 @@ __device__ __forceinline__ bool yp_iou_gt(const float4 a, const float4 b, float 
     if (inter < pr * (1.0f - 0x1p-21f)) return false;
   }
   return (inter == 0.0f ? 0.0f : inter / uni) > thr;
+}
+
+// Pair number x of the strict upper triangle, rows first: x = j*(j-1)/2 + i with i < j.
+__device__ __forceinline__ void tri_pair(int x, int& i, int& j) {
+  int jj = (int)((1.0f + __builtin_sqrtf(1.0f + 8.0f * (float)x)) * 0.5f);
+  while (jj * (jj - 1) / 2 > x) --jj;
+  while ((jj + 1) * jj / 2 <= x) ++jj;
+  j = jj;
+  i = x - jj * (jj - 1) / 2;
 }
 
 // Output row r of image b: sanitize + normalise (detection.py:92-98), class/score/index
@@ -405,15 +467,12 @@ __device__ void finish_image(const NmsArgs& p, int b, int n, int survivors) {
 template <int THREADS>
 __device__ bool fast_nms_keep(const float4* sbox, int* ssup, int* s_wave_cnt, int k, float thr, int& pos, int& total) {
   const int t = threadIdx.x;
-  int sz = 64;                       // columns rounded up to a power of two; the rest of the
-  while (sz < k) sz <<= 1;           // workgroup's threads split each column's rows
-  const int G = THREADS / sz;
-  const int j = t & (sz - 1), g = t / sz;
-  if (j < k && g < G) {
-    const float4 bj = sbox[j];
-    bool sup = false;
-    for (int i = g; i < j; i += G) sup = sup || yp_iou_gt(sbox[i], bj, thr);
-    if (sup) ssup[j] = 1;
+  // the k*(k-1)/2 pairs are dealt evenly to the threads: independent iterations, no long column
+  const int npairs = k * (k - 1) / 2;
+  for (int x = t; x < npairs; x += THREADS) {
+    int i, j;
+    tri_pair(x, i, j);
+    if (yp_iou_gt(sbox[i], sbox[j], thr)) ssup[j] = 1;
   }
   __syncthreads();
   bool keep = false;
@@ -542,6 +601,8 @@ __global__ __launch_bounds__(THREADS) void group_nms_kernel(const NmsArgs p) {
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int g = blockIdx.x, b = blockIdx.y;
   u64* const pool = p.pool + ((size_t)b * p.ngroups + g) * p.gcap;
+  STAMP_INIT(0, b * p.ngroups + g);
+  STAMP(0);
   // 1. one pass over the image's lists (a few tens of KB, shared by the image's workgroups through
   //    L2): this group's keys into LDS, class histogram on the way
   if (t < 256) { gs.cls_cnt[t] = 0; gs.cls_fill[t] = 0; }
@@ -555,6 +616,7 @@ __global__ __launch_bounds__(THREADS) void group_nms_kernel(const NmsArgs p) {
   });
   __syncthreads();
   const int m = gs.fill;
+  STAMP(1);
   if (m == 0) {
     if (t == 0) p.pool_count[(size_t)b * p.ngroups + g] = 0;
     return;
@@ -570,11 +632,7 @@ __global__ __launch_bounds__(THREADS) void group_nms_kernel(const NmsArgs p) {
   int cv = 0, incl = 0;
   if (t < 256) {
     cv = gs.cls_cnt[t];
-    incl = cv;
-    for (int o = 1; o < 64; o <<= 1) {
-      const int u = __shfl_up(incl, o);
-      if (lane >= o) incl += u;
-    }
+    incl = wave_incl_scan(cv);
     if (lane == 63) gs.sh.wtot[wave] = incl;
   }
   __syncthreads();
@@ -584,6 +642,7 @@ __global__ __launch_bounds__(THREADS) void group_nms_kernel(const NmsArgs p) {
     gs.cls_off[t] = base + incl - cv;
   }
   __syncthreads();
+  STAMP(2);
   // 3. bucket by class (the order inside a bucket is arbitrary; the ranks below do not depend on it)
   for (int i = t; i < m; i += THREADS) {
     const u64 key = gs.a[i];
@@ -594,6 +653,7 @@ __global__ __launch_bounds__(THREADS) void group_nms_kernel(const NmsArgs p) {
     gs.psup[pos] = 0;
   }
   __syncthreads();
+  STAMP(3);
   // 4. per candidate: fetch prior + offsets (one round trip for the whole group), rank inside the
   //    class (= number of larger keys: tf.math.top_k order, detection.py:217), decode, and move key
   //    and box to the sorted position if the rank is inside top_k (detection.py:219)
@@ -624,23 +684,23 @@ __global__ __launch_bounds__(THREADS) void group_nms_kernel(const NmsArgs p) {
     }
   }
   __syncthreads();
+  STAMP(4);
   // 5. Fast NMS inside every class: a candidate survives unless a higher-ranked box of its class
   //    overlaps it by more than the threshold (detection.py:221-234; every candidate has p > conf)
-  //    Four lanes share a candidate's rows: the loop is a chain of LDS round trips, so its length,
-  //    not its instruction count, is what costs.
-  for (int w = t; w < 4 * m; w += THREADS) {
-    const int i = w >> 2, sub = w & 3;
-    const int c = gs.pcls[i];
+  //    Class by class, the pairs (i < j) of a class dealt evenly to all threads: independent
+  //    iterations instead of one long chain of LDS round trips per candidate.
+  for (int c = g + 1; c <= p.nseg; c += p.ngroups) {
     const int lo = gs.cls_off[c];
-    const int r = i - lo;
-    if (r < min(gs.cls_cnt[c], p.top_k)) {
-      const float4 bj = gs.box[i];
-      bool sup = false;
-      for (int q = sub; q < r && !sup; q += 4) sup = yp_iou_gt(gs.box[lo + q], bj, p.nms_thresh);
-      if (sup) gs.psup[i] = 1;
+    const int kc = min(gs.cls_cnt[c], p.top_k);
+    const int npairs = kc * (kc - 1) / 2;
+    for (int x = t; x < npairs; x += THREADS) {
+      int i, j;
+      tri_pair(x, i, j);
+      if (yp_iou_gt(gs.box[lo + i], gs.box[lo + j], p.nms_thresh)) gs.psup[lo + j] = 1;
     }
   }
   __syncthreads();
+  STAMP(5);
   for (int i = t; i < m; i += THREADS) {
     const int c = gs.pcls[i];
     if (gs.psup[i] == 0 && i - gs.cls_off[c] < min(gs.cls_cnt[c], p.top_k)) {
@@ -649,10 +709,12 @@ __global__ __launch_bounds__(THREADS) void group_nms_kernel(const NmsArgs p) {
     }
   }
   __syncthreads();
+  STAMP(6);
   // 6. the group's survivors, dense, for the cross-class selection (detection.py:234-239)
   const int np = gs.npool;
   for (int i = t; i < np; i += THREADS) pool[i] = gs.bk[i];
   if (t == 0) p.pool_count[(size_t)b * p.ngroups + g] = np;
+  STAMP(7);
 }
 
 // Per-class mode: cross-class top max_dets over the pooled survivors (detection.py:242-248).
@@ -663,6 +725,8 @@ __global__ __launch_bounds__(THREADS) void final_select_kernel(const NmsArgs p) 
   __shared__ int start[32];
   const int t = threadIdx.x;
   const int b = blockIdx.x;
+  STAMP_INIT(1, b);
+  STAMP(0);
   if (t == 0) {
     int acc = 0;
     for (int g = 0; g < p.ngroups; ++g) { start[g] = acc; acc += p.pool_count[(size_t)b * p.ngroups + g]; }
@@ -672,10 +736,16 @@ __global__ __launch_bounds__(THREADS) void final_select_kernel(const NmsArgs p) 
   for (int i = t; i < p.parts; i += THREADS) part += p.seg_surv[(size_t)b * p.parts + i];
   const int survivors = block_sum<THREADS>(part, sh.wtot);   // (its barriers also publish start[])
   const int n = start[p.ngroups];
+  STAMP(1);
   int k = 0;
   if (n > 0) {
     const PoolSrc src{p.pool + (size_t)b * p.ngroups * p.gcap, start, p.ngroups, p.gcap};
+#ifdef YP_STAMPS
+    k = select_topk_sorted<THREADS>(src, n, min(p.max_dets, YP_SORT_MAX), sh, stage, dbg_);
+#else
     k = select_topk_sorted<THREADS>(src, n, min(p.max_dets, YP_SORT_MAX), sh, stage);
+#endif
+    STAMP(2);
     if (t < k) {
       const u64 key = sh.key[t];
       const int anchor = min(yp_fin_key_anchor(key), p.A - 1);
@@ -685,7 +755,9 @@ __global__ __launch_bounds__(THREADS) void final_select_kernel(const NmsArgs p) 
       emit_row(p, b, t, yp_key_score(key), yp_fin_key_class(key), anchor, yp_decode(pr, of), cf);
     }
   }
+  STAMP(3);
   finish_image<THREADS>(p, b, k, survivors);
+  STAMP(4);
 }
 
 static NmsArgs make_args(const yp_handle* h, int batch, const float* pred_offset, const float* priors, const float* pred_mask_coef,
@@ -705,6 +777,9 @@ static NmsArgs make_args(const yp_handle* h, int batch, const float* pred_offset
   a.use_crop = h->cfg.use_cropped_mask;
   yp_plan_items(h, batch, &a.parts, &a.cap_item);
   yp_plan_groups(h, &a.ngroups, &a.gcap);
+#ifdef YP_STAMPS
+  a.dbg = (unsigned long long*)h->dbg;
+#endif
   return a;
 }
 
