@@ -113,7 +113,17 @@ struct PartSrc {   // score_filter's lists of one image: nparts lists of `cap` s
       const int j = s >> sft, q = s & (lpp - 1);
       const int n = counts[j];
       const u64* l = base + (size_t)j * cap;
-      for (int i0 = q; i0 < n; i0 += lpp * YP_PART_UNROLL) {
+      {
+        // first batch: issued without waiting for the count (slots past it hold stale keys, still
+        // inside the list's allocation), so count and keys share one round trip
+        u64 k[YP_PART_UNROLL];
+#pragma unroll
+        for (int u = 0; u < YP_PART_UNROLL; ++u) k[u] = l[min((long long)(q + u * lpp), cap - 1)];
+#pragma unroll
+        for (int u = 0; u < YP_PART_UNROLL; ++u)
+          if (q + u * lpp < n && take(k[u])) f(k[u]);
+      }
+      for (int i0 = q + lpp * YP_PART_UNROLL; i0 < n; i0 += lpp * YP_PART_UNROLL) {
         u64 k[YP_PART_UNROLL];
 #pragma unroll
         for (int u = 0; u < YP_PART_UNROLL; ++u) k[u] = l[min(i0 + u * lpp, n - 1)];
@@ -194,7 +204,7 @@ __device__ __forceinline__ int lds_append_slot(int* counter) {
   const int leader = __ffsll((long long)act) - 1;
   int base = 0;
   if (lane == leader) base = atomicAdd(counter, __popcll(act));
-  base = __shfl(base, leader);
+  base = __builtin_amdgcn_readlane(base, leader);   // leader is wave-uniform
   return base + __popcll(act & ((1ull << lane) - 1ull));
 }
 
@@ -399,13 +409,20 @@ __device__ __forceinline__ bool yp_iou_gt(const float4 a, const float4 b, float 
   return (inter == 0.0f ? 0.0f : inter / uni) > thr;
 }
 
-// Pair number x of the strict upper triangle, rows first: x = j*(j-1)/2 + i with i < j.
-__device__ __forceinline__ void tri_pair(int x, int& i, int& j) {
-  int jj = (int)((1.0f + __builtin_sqrtf(1.0f + 8.0f * (float)x)) * 0.5f);
-  while (jj * (jj - 1) / 2 > x) --jj;
-  while ((jj + 1) * jj / 2 <= x) ++jj;
-  j = jj;
-  i = x - jj * (jj - 1) / 2;
+// The n*(n-1)/2 unordered pairs of n items as a rectangle of n rows and n/2 columns: entry (r, c)
+// pairs r with (r + 1 + c) mod n.  Every pair appears once; for even n the last column is the
+// pairs at distance n/2, valid for r < n/2 only.  tri_count() entries in all; tri_pair() returns
+// false for the invalid ones.  (x + 0.5) / w in float is exact here: x < 2^15, w <= 128.)
+__device__ __forceinline__ int tri_count(int n) { return n * (n >> 1); }
+__device__ __forceinline__ bool tri_pair(int x, int n, int& i, int& j) {
+  const int w = n >> 1;
+  const int r = (int)(((float)x + 0.5f) * (1.0f / (float)w));
+  const int c = x - r * w;
+  int q = r + 1 + c;
+  q = q >= n ? q - n : q;
+  i = min(r, q);
+  j = max(r, q);
+  return (n & 1) || c < w - 1 || r < w;
 }
 
 // Output row r of image b: sanitize + normalise (detection.py:92-98), class/score/index
@@ -468,11 +485,10 @@ template <int THREADS>
 __device__ bool fast_nms_keep(const float4* sbox, int* ssup, int* s_wave_cnt, int k, float thr, int& pos, int& total) {
   const int t = threadIdx.x;
   // the k*(k-1)/2 pairs are dealt evenly to the threads: independent iterations, no long column
-  const int npairs = k * (k - 1) / 2;
+  const int npairs = tri_count(k);
   for (int x = t; x < npairs; x += THREADS) {
     int i, j;
-    tri_pair(x, i, j);
-    if (yp_iou_gt(sbox[i], sbox[j], thr)) ssup[j] = 1;
+    if (tri_pair(x, k, i, j) && yp_iou_gt(sbox[i], sbox[j], thr)) ssup[j] = 1;
   }
   __syncthreads();
   bool keep = false;
@@ -692,11 +708,10 @@ __global__ __launch_bounds__(THREADS) void group_nms_kernel(const NmsArgs p) {
   for (int c = g + 1; c <= p.nseg; c += p.ngroups) {
     const int lo = gs.cls_off[c];
     const int kc = min(gs.cls_cnt[c], p.top_k);
-    const int npairs = kc * (kc - 1) / 2;
+    const int npairs = tri_count(kc);
     for (int x = t; x < npairs; x += THREADS) {
       int i, j;
-      tri_pair(x, i, j);
-      if (yp_iou_gt(gs.box[lo + i], gs.box[lo + j], p.nms_thresh)) gs.psup[lo + j] = 1;
+      if (tri_pair(x, kc, i, j) && yp_iou_gt(gs.box[lo + i], gs.box[lo + j], p.nms_thresh)) gs.psup[lo + j] = 1;
     }
   }
   __syncthreads();
