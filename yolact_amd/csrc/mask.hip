@@ -127,7 +127,21 @@ __global__ __launch_bounds__(YP_MASK_BLOCK) void mask_assemble_kernel(const Mask
   const uint32_t voff = (uint32_t)t * 4u;
   const uint32_t rstride = (uint32_t)p.P * 4u;
   const bool plain = !NT_STORE && brow == nullptr;
-  if (live) {
+  const bool wide = plain && (p.P & 3) == 0 && ((uintptr_t)p.masks & 15u) == 0;
+  if (wide) {
+    // the workgroup's 256 pixels of a row are 1 KiB: one 16-byte store per lane zeroes a whole row
+    // segment (eight full lines), wave w taking rows w, w+4, ...  The rows are then rewritten by the
+    // waves that own their pixels, so these stores must have completed first.
+    const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
+    if (lane < (npx >> 2)) {
+      uint32_t vo = (uint32_t)lane * 16u + (uint32_t)wv * rstride;
+      const nat4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
+      for (int n = wv; n < N; n += YP_MASK_BLOCK / 64, vo += (YP_MASK_BLOCK / 64) * rstride)
+        asm volatile("global_store_dwordx4 %0, %1, %2" ::"v"(vo), "v"(zero4), "s"(orow) : "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  } else if (live) {
     if (plain) {
       uint32_t vo = voff;
       const float zero = 0.0f;
@@ -196,7 +210,14 @@ hipError_t yp_launch_mask_assemble(const yp_handle* h, int batch, const float* p
   const bool nt = getenv("YP_MASK_NT") ? atoi(getenv("YP_MASK_NT")) != 0 : false;
   const int bpi = (a.P + YP_MASK_BLOCK - 1) / YP_MASK_BLOCK;
   const dim3 grid(8 * ((batch + 7) / 8) * bpi);
-  if (nt) hipLaunchKernelGGL((mask_assemble_kernel<true>), grid, dim3(YP_MASK_BLOCK), 0, st, a, bpi, batch);
-  else hipLaunchKernelGGL((mask_assemble_kernel<false>), grid, dim3(YP_MASK_BLOCK), 0, st, a, bpi, batch);
+  // Residency by LDS padding.  Masks that fit the 256 MiB Infinity Cache are absorbed there and the
+  // kernel wants as many waves as it can get (8 workgroups per CU).  Larger outputs stream to HBM,
+  // where fewer concurrent write streams keep more DRAM pages open: 2 workgroups per CU measured
+  // best (config 5: 499 -> 442 us).
+  const size_t out_bytes = (size_t)batch * a.max_dets * a.P * sizeof(float);
+  size_t pad = out_bytes > ((size_t)256 << 20) ? 66000 : 0;
+  if (const char* ev = getenv("YP_MASK_LDS_PAD")) pad = (size_t)atoi(ev);   // tuning knob
+  if (nt) hipLaunchKernelGGL((mask_assemble_kernel<true>), grid, dim3(YP_MASK_BLOCK), pad, st, a, bpi, batch);
+  else hipLaunchKernelGGL((mask_assemble_kernel<false>), grid, dim3(YP_MASK_BLOCK), pad, st, a, bpi, batch);
   return hipGetLastError();
 }
