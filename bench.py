@@ -122,8 +122,6 @@ def main():
     for i in range(args.warmup):
         step(i)
     barrier()
-    if os.environ.get("YP_SF_ABL_AFTER_WARMUP"):   # diagnostic builds only (tools/sf_ablate.sh)
-        os.environ["YP_SF_ABL"] = os.environ["YP_SF_ABL_AFTER_WARMUP"]
     kern_ms = {}
     t0 = time.perf_counter()
     for i in range(args.steps):
