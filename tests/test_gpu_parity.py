@@ -233,3 +233,39 @@ def test_full_size_batch32_properties_and_oracle(torch_cuda):
             rows_out = np.r_[0:int(np.floor(y1[i]))]
             assert not m[i, rows_out].any()
             assert not m[i, int(np.ceil(y2[i])) + 1:].any()
+
+
+def test_per_class_large_groups_and_classes(torch_cuda):
+    """Two foreground classes with ~1000 candidates each: the class-group workgroups leave their
+    thread-per-candidate path (> 1024 candidates) for the class-by-class one, whose select has more
+    than 256 keys to choose from."""
+    from yolact_amd import synth
+    net, shp = synth.make_toy(21, batch=2, fmaps=((32, 32), (8, 8)), num_classes=3, p_fg=0.9)   # A = 3264
+    got, ref = check_vs_c_oracle(torch_cuda, net, shp, mode="per_class", top_k=200, max_dets=100, label="large-groups")
+    assert (ref["num_survivors"] > 2200).all()
+    check_vs_c_oracle(torch_cuda, net, shp, mode="cc", top_k=256, max_dets=300, label="large-groups-cc")
+
+
+def test_more_work_items_than_resident_waves(torch_cuda):
+    """4000 small images: score_filter has more work items than resident waves and walks them
+    grid-stride; every NMS workgroup finds one list per image."""
+    from yolact_amd import synth
+    net, shp = synth.make_toy(22, batch=4000)
+    for mode, top_k, max_dets in (("cc", 15, 15), ("per_class", 30, 10)):
+        check_vs_c_oracle(torch_cuda, net, shp, mode=mode, top_k=top_k, max_dets=max_dets, label=f"many-items-{mode}")
+
+
+def test_odd_proto_size_takes_the_narrow_zero_stores(torch_cuda):
+    """P = 13*11 is not a multiple of 4: mask rows are not 16-byte aligned and the zero pass stores dwords."""
+    from yolact_amd import synth
+    net, shp = synth.make_toy(23, proto_hw=(13, 11))
+    check_vs_c_oracle(torch_cuda, net, shp, mode="cc", top_k=50, max_dets=40, label="oddP")
+    check_vs_c_oracle(torch_cuda, net, shp, mode="per_class", top_k=50, max_dets=40, label="oddP")
+
+
+def test_masks_larger_than_the_infinity_cache(torch_cuda):
+    """Config 3 shape, 6 images x 300 rows: 354 MB of masks, the low-residency launch of mask_assemble."""
+    from yolact_amd import synth
+    cfg = synth.CONFIGS[3]
+    net, shp = synth.make_batch(cfg, batch=6)
+    check_vs_c_oracle(torch_cuda, net, shp, mode="cc", top_k=200, max_dets=300, label="big-masks")
