@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define YP_VERSION 100 /* 0.1.0 */
+#define YP_VERSION 101 /* 0.1.1 */
 
 enum {
   YP_OK = 0,
@@ -114,6 +114,17 @@ int yp_last_survivors(yp_handle* h, int32_t* host_out, int32_t batch);
 #define YP_NUM_KERNELS 4
 int yp_profile_enable(yp_handle* h, int32_t on);
 int yp_profile_read(yp_handle* h, float* ms_out /* [YP_NUM_KERNELS] */);
+
+/* Anchor._generate_anchors + Anchor.get_anchors (data/anchor.py:23-68): the `priors` tensor Detect
+ * consumes, built on the device.  fmap_hw = [num_levels][2] feature-map (height, width)
+ * (yolact.py:75-86), scales = one per level, aspect_ratios = num_ratios values (train.py:65-68);
+ * 1..8 of each.  Writes [A,4] float32 [ymin,xmin,ymax,xmax] pixels in the reference's anchor
+ * order (level, row, column, ratio) to `priors` (device, 16-byte aligned, room for `capacity`
+ * anchors), asynchronously on hip_stream, and returns A.  With priors == NULL nothing is launched
+ * and A is returned (size query; works without a device).  Negative YP_E* code on failure. */
+int64_t yp_make_priors(int32_t img_h, int32_t img_w, int32_t num_levels, const int32_t* fmap_hw,
+                       const double* scales, int32_t num_ratios, const double* aspect_ratios,
+                       float* priors, int64_t capacity, int32_t device_id, void* hip_stream);
 
 /* Bytes of device scratch the handle holds. */
 int64_t yp_scratch_bytes(const yp_handle* h);

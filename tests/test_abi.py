@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     assert set(syms) == set(_lib.EXPORTS), (syms, _lib.EXPORTS)
     for s in syms:
         assert hasattr(L, s), s
-    assert L.yp_version() == 100
+    assert L.yp_version() == 101
 
 
 def test_config_struct_matches_header():
@@ -104,3 +104,21 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".h")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in text.lower(), os.path.join(dirpath, f)
+
+
+def test_make_priors_size_query_and_errors():
+    """yp_make_priors (data/anchor.py:23-68 on the device): the size query and argument checks need no GPU."""
+    import ctypes
+    from yolact_amd import _lib
+    from yolact_amd.anchors import feature_map_sizes
+    L = _lib.load()
+    fm = feature_map_sizes(550, 550)
+    c_fm = (ctypes.c_int32 * 10)(*[v for hw in fm for v in hw])
+    c_sc = (ctypes.c_double * 5)(24, 48, 96, 192, 384)
+    c_ar = (ctypes.c_double * 3)(1.0, 0.5, 2.0)
+    assert L.yp_make_priors(550, 550, 5, c_fm, c_sc, 3, c_ar, None, 0, 0, None) == 19248
+    assert L.yp_make_priors(550, 550, 9, c_fm, c_sc, 3, c_ar, None, 0, 0, None) < 0
+    assert b"levels" in L.yp_last_error()
+    c_bad = (ctypes.c_double * 3)(1.0, -0.5, 2.0)
+    assert L.yp_make_priors(550, 550, 5, c_fm, c_sc, 3, c_bad, None, 0, 0, None) < 0
+    assert L.yp_make_priors(0, 550, 5, c_fm, c_sc, 3, c_ar, None, 0, 0, None) < 0

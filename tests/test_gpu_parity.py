@@ -269,3 +269,27 @@ def test_masks_larger_than_the_infinity_cache(torch_cuda):
     cfg = synth.CONFIGS[3]
     net, shp = synth.make_batch(cfg, batch=6)
     check_vs_c_oracle(torch_cuda, net, shp, mode="cc", top_k=200, max_dets=300, label="big-masks")
+
+
+@pytest.mark.parametrize("hw", [(550, 550), (768, 1024), (800, 1333), (64, 64)])
+def test_device_priors_bit_exact(torch_cuda, hw):
+    """yp_make_priors against the line-by-line restatement of data/anchor.py:23-68 (and the host numpy
+    generator the synthetic inputs use): every float bit-identical, anchors in the reference's order."""
+    from oracle import detect_oracle as po
+    from yolact_amd import anchors
+    H, W = hw
+    if hw == (64, 64):
+        fm, scales = ((8, 8), (4, 4), (1, 3)), (12, 24, 50.5)
+    else:
+        fm, scales = anchors.feature_map_sizes(H, W), anchors.DEFAULT_SCALES
+    ratios = (1.0, 0.5, 2.0)
+    got = anchors.make_priors_device(H, W, feature_maps=fm, aspect_ratios=ratios, scales=scales)
+    torch_cuda.cuda.synchronize()
+    got = got.cpu().numpy()
+    ref = po.generate_anchors(H, W, fm, ratios, scales)
+    assert got.shape == ref.shape and got.dtype == np.float32
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+    host = anchors.make_priors(H, W, feature_maps=fm, aspect_ratios=ratios, scales=scales)
+    assert np.array_equal(host.view(np.uint32), ref.view(np.uint32))
+    assert anchors.make_priors_device(H, W, feature_maps=fm, aspect_ratios=ratios, scales=scales).data_ptr() == \
+        anchors.make_priors_device(H, W, feature_maps=fm, aspect_ratios=ratios, scales=scales).data_ptr()   # cached

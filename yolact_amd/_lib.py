@@ -18,7 +18,7 @@ KERNEL_NAMES = ("score_filter", "segment_nms", "final_select", "mask_assemble")
 
 # every symbol include/yolact_post.h declares
 EXPORTS = ("yp_create", "yp_destroy", "yp_run", "yp_sync", "yp_last_survivors", "yp_profile_enable",
-           "yp_profile_read", "yp_scratch_bytes", "yp_last_error", "yp_version")
+           "yp_profile_read", "yp_scratch_bytes", "yp_last_error", "yp_version", "yp_make_priors")
 
 
 class YpConfig(ctypes.Structure):
@@ -71,6 +71,10 @@ def load():
     L.yp_scratch_bytes.argtypes = [vp]
     L.yp_last_error.restype = ctypes.c_char_p
     L.yp_last_error.argtypes = []
+    L.yp_make_priors.restype = ctypes.c_int64
+    L.yp_make_priors.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(ctypes.c_int32),
+                                 ctypes.POINTER(ctypes.c_double), ctypes.c_int32, ctypes.POINTER(ctypes.c_double), vp,
+                                 ctypes.c_int64, ctypes.c_int32, vp]
     L.yp_version.restype = ctypes.c_int
     L.yp_version.argtypes = []
     _lib = L

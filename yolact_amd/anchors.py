@@ -65,3 +65,43 @@ def make_priors(img_h: int, img_w: int, feature_maps=None, aspect_ratios=DEFAULT
     w, h = cxcywh[:, 2], cxcywh[:, 3]
     return np.stack([cxcywh[:, 1] - h / two, cxcywh[:, 0] - w / two,
                      cxcywh[:, 1] + h / two, cxcywh[:, 0] + w / two], axis=-1).astype(np.float32)
+
+
+_DEVICE_PRIORS = {}
+
+
+def make_priors_device(img_h: int, img_w: int, feature_maps=None, aspect_ratios=DEFAULT_ASPECT_RATIOS,
+                       scales=DEFAULT_SCALES, device=0):
+    """The same [A,4] priors built on the GPU by ``yp_make_priors`` (csrc/priors.hip), cached per
+    (shape, scales, ratios, device) like the reference's one-time ``Anchor`` object (yolact.py:98-104).
+    Returns a torch CUDA tensor; raises without the library or a HIP device."""
+    import ctypes
+
+    import torch
+
+    from . import _lib
+    if feature_maps is None:
+        feature_maps = feature_map_sizes(img_h, img_w)
+    dev = torch.device("cuda", device) if isinstance(device, int) else torch.device(device)
+    fm = tuple((int(h), int(w)) for h, w in feature_maps)
+    sc = tuple(float(x) for x in scales)[:len(fm)]
+    ar = tuple(float(x) for x in aspect_ratios)
+    key = (int(img_h), int(img_w), fm, sc, ar, dev.index)
+    hit = _DEVICE_PRIORS.get(key)
+    if hit is not None:
+        return hit
+    L = _lib.load()
+    c_fm = (ctypes.c_int32 * (2 * len(fm)))(*[v for hw in fm for v in hw])
+    c_sc = (ctypes.c_double * len(sc))(*sc)
+    c_ar = (ctypes.c_double * len(ar))(*ar)
+    n = L.yp_make_priors(img_h, img_w, len(fm), c_fm, c_sc, len(ar), c_ar, None, 0, dev.index or 0, None)
+    if n < 0:
+        _lib.check(int(n))
+    out = torch.empty((int(n), 4), dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    rc = L.yp_make_priors(img_h, img_w, len(fm), c_fm, c_sc, len(ar), c_ar, out.data_ptr(), int(n), dev.index or 0,
+                          ctypes.c_void_p(stream))
+    if rc < 0:
+        _lib.check(int(rc))
+    _DEVICE_PRIORS[key] = out
+    return out

@@ -224,4 +224,27 @@ extern "C" int yp_debug_stamps(yp_handle* h, unsigned long long* host_out) {
 }
 #endif
 
+extern "C" int64_t yp_make_priors(int32_t img_h, int32_t img_w, int32_t num_levels, const int32_t* fmap_hw, const double* scales,
+                                  int32_t num_ratios, const double* aspect_ratios, float* priors, int64_t capacity,
+                                  int32_t device_id, void* hip_stream) {
+  if (!fmap_hw || !scales || !aspect_ratios) return fail(YP_EINVAL, "yp_make_priors: null argument");
+  if (img_h < 1 || img_w < 1) return fail(YP_EINVAL, "yp_make_priors: bad image size");
+  const long long n = yp_priors_count(num_levels, fmap_hw, num_ratios);
+  if (n < 0) return fail(YP_EINVAL, "yp_make_priors: 1..8 levels with positive sizes and 1..8 aspect ratios are supported");
+  double sq[8];
+  for (int k = 0; k < num_ratios; ++k) {
+    if (!(aspect_ratios[k] > 0.0)) return fail(YP_EINVAL, "yp_make_priors: aspect ratios must be positive");
+    sq[k] = sqrt(aspect_ratios[k]);                                    // anchor.py:40
+  }
+  if (!priors) return n;                                               // size query
+  if (capacity < n) return fail(YP_EINVAL, "yp_make_priors: %lld anchors do not fit a buffer of %lld", n, (long long)capacity);
+  if ((((uintptr_t)priors) & 15u) != 0) return fail(YP_EINVAL, "yp_make_priors: priors must be 16-byte aligned");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(YP_ENODEV, "no HIP device available");
+  if (device_id < 0 || device_id >= ndev) return fail(YP_ENODEV, "device_id %d out of range (%d devices)", device_id, ndev);
+  YP_HIP(hipSetDevice(device_id));
+  YP_HIP(yp_launch_make_priors(img_h, img_w, num_levels, fmap_hw, scales, num_ratios, sq, priors, (hipStream_t)hip_stream));
+  return n;
+}
+
 extern "C" int64_t yp_scratch_bytes(const yp_handle* h) { return h ? h->scratch_bytes : 0; }

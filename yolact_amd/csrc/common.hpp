@@ -167,6 +167,9 @@ static inline void yp_plan_groups(const yp_handle* h, int* ngroups, int* gcap) {
 int yp_score_filter_waves_per_cu(const yp_handle* h);
 
 // Kernel launchers (one per translation unit).  All asynchronous on `st`.
+long long yp_priors_count(int num_levels, const int32_t* fmap_hw, int num_ratios);
+hipError_t yp_launch_make_priors(int img_h, int img_w, int num_levels, const int32_t* fmap_hw, const double* scales,
+                                 int num_ratios, const double* sqrt_ratios, float* priors, hipStream_t st);
 hipError_t yp_launch_score_filter(const yp_handle* h, int batch, const float* pred_cls, hipStream_t st);
 hipError_t yp_launch_segment_nms(const yp_handle* h, int batch, const float* pred_offset, const float* priors,
                                  const float* pred_mask_coef, float* det_boxes,
