@@ -34,18 +34,27 @@ __device__ __forceinline__ float dpp_f(float v) {
 }
 template <int CTRL>
 __device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, false); }
-#define YP_DPP_ROR(n) (0x120 + (n))   // row_ror:n  - lane j reads lane (j+n) mod 16 of its row
 #define YP_DPP_XOR1 0xB1              // quad_perm:[1,0,3,2]
 
-// YP-MATH tree over the 16 strided partial sums held by a row of 16 lanes: level 1 pairs (j, j+8),
-// level 2 (j, j+4), level 3 (j, j+2), level 4 (j, j+1).  After level k the values are periodic with
-// period 16 >> k, so a rotation by the period pairs exactly those operands (IEEE add commutes) and
-// every lane ends up with the identical total.
-__device__ __forceinline__ float grp16_sum(float v) {
-  v = v + dpp_f<YP_DPP_ROR(8)>(v);
-  v = v + dpp_f<YP_DPP_ROR(4)>(v);
-  v = v + dpp_f<YP_DPP_ROR(2)>(v);
-  v = v + dpp_f<YP_DPP_ROR(1)>(v);
+#define YP_DPP_XOR2 0x4E              // quad_perm:[2,3,0,1]
+// lane j of a group of 8 (half a DPP row) reads lane j ^ 4: row_shl:4 for the lower four lanes of
+// every group (banks 0 and 2 of the row), row_shr:4 for the upper four (banks 1 and 3)
+__device__ __forceinline__ int xor4_i(int v) {
+  int t = __builtin_amdgcn_update_dpp(0, v, 0x104, 0xF, 0x5, false);
+  return __builtin_amdgcn_update_dpp(t, v, 0x114, 0xF, 0xA, false);
+}
+__device__ __forceinline__ float xor4_f(float v) { return __builtin_bit_cast(float, xor4_i(__builtin_bit_cast(int, v))); }
+
+// YP-MATH tree over the 16 strided partial sums of one anchor, held two per lane by a group of 8
+// lanes: lane j has s_j (classes j, j+16, ...) and s_{j+8} (classes j+8, j+24, ...).  Level 1 pairs
+// (j, j+8): in the lane.  Level 2 (j, j+4), level 3 (j, j+2), level 4 (j, j+1): after level k the
+// values are periodic with period 16 >> k, so exchanging with lane j^4, j^2, j^1 pairs exactly those
+// operands (IEEE add commutes) and every lane ends up with the identical total.
+__device__ __forceinline__ float grp8_sum(float s_lo, float s_hi) {
+  float v = s_lo + s_hi;
+  v = v + xor4_f(v);
+  v = v + dpp_f<YP_DPP_XOR2>(v);
+  v = v + dpp_f<YP_DPP_XOR1>(v);
   return v;
 }
 // max of three floats in one instruction (no NaN canonicalisation passes; logits are finite)
@@ -54,30 +63,27 @@ __device__ __forceinline__ float max3f(float a, float b, float c) {
   asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
   return d;
 }
-// max over a row of 16 lanes of NON-NEGATIVE floats: their bit patterns order like integers
-__device__ __forceinline__ float grp16_max_nonneg(float f) {
+// max over a group of 8 lanes of NON-NEGATIVE floats: their bit patterns order like integers
+__device__ __forceinline__ float grp8_max_nonneg(float f) {
   int v = __builtin_bit_cast(int, f);
-  v = max(v, dpp_i<YP_DPP_ROR(8)>(v));
-  v = max(v, dpp_i<YP_DPP_ROR(4)>(v));
-  v = max(v, dpp_i<YP_DPP_ROR(2)>(v));
-  v = max(v, dpp_i<YP_DPP_ROR(1)>(v));
+  v = max(v, xor4_i(v));
+  v = max(v, dpp_i<YP_DPP_XOR2>(v));
+  v = max(v, dpp_i<YP_DPP_XOR1>(v));
   return __builtin_bit_cast(float, v);
 }
 __device__ __forceinline__ float max_nonneg(float a, float b) {
   return __builtin_bit_cast(float, max(__builtin_bit_cast(int, a), __builtin_bit_cast(int, b)));
 }
-__device__ __forceinline__ int grp16_sum_i(int v) {
-  v = v + dpp_i<YP_DPP_ROR(8)>(v);
-  v = v + dpp_i<YP_DPP_ROR(4)>(v);
-  v = v + dpp_i<YP_DPP_ROR(2)>(v);
-  v = v + dpp_i<YP_DPP_ROR(1)>(v);
+__device__ __forceinline__ int grp8_sum_i(int v) {
+  v = v + xor4_i(v);
+  v = v + dpp_i<YP_DPP_XOR2>(v);
+  v = v + dpp_i<YP_DPP_XOR1>(v);
   return v;
 }
-__device__ __forceinline__ int grp16_min(int v) {
-  v = min(v, dpp_i<YP_DPP_ROR(8)>(v));
-  v = min(v, dpp_i<YP_DPP_ROR(4)>(v));
-  v = min(v, dpp_i<YP_DPP_ROR(2)>(v));
-  v = min(v, dpp_i<YP_DPP_ROR(1)>(v));
+__device__ __forceinline__ int grp8_min(int v) {
+  v = min(v, xor4_i(v));
+  v = min(v, dpp_i<YP_DPP_XOR2>(v));
+  v = min(v, dpp_i<YP_DPP_XOR1>(v));
   return v;
 }
 
@@ -93,15 +99,18 @@ __device__ __forceinline__ int grp16_min(int v) {
 //            x_bg, max foreground logit, row max; exact-safe early reject:
 //            p_fgmax <= 1/(1+exp(x_bg-x_fgmax)), so an anchor with x_bg-x_fgmax >= ln(1/conf-1)+1e-3
 //            cannot pass `class_p_max > conf` (detection.py:73) and needs no exponentials at all
-//   phase 2  the remaining anchors, four at a time, 16 lanes per anchor: lane j owns classes
-//            j, j+16, ... - exactly the 16 strided partial sums of the YP-MATH softmax - so the
-//            denominator is a per-lane sequential sum plus one DPP tree (8,4,2,1)
+//   phase 2  the remaining anchors, eight at a time, 8 lanes per anchor: lane j owns classes
+//            j, j+8, j+16, ... and keeps two running sums (even and odd terms) - exactly the strided
+//            partial sums s_j and s_{j+8} of the YP-MATH softmax - so the denominator is two per-lane
+//            sequential sums plus one tree ((j,j+8) in the lane, then j^4, j^2, j^1 by DPP).  Eight
+//            anchors per round amortise the trees, the division and the bookkeeping over twice as
+//            many anchors as sixteen lanes per anchor did: the kernel is bound by instruction issue.
 //   phase 3  keys collect in LDS and leave in runs of >= 64 for the item's list
 template <int MODE, int CPL>
 __global__ __launch_bounds__(YP_WAVE) void score_filter_kernel(const ScoreFilterArgs p) {
   constexpr int TA = YP_SF_TA;
   constexpr int LPA = YP_WAVE / TA;   // lanes per anchor in phase 1
-  constexpr int NLD = (TA * CPL) / 16;   // 1 KiB wave-loads that cover TA rows of up to 16*CPL floats
+  constexpr int NLD = (TA * CPL) / 32;   // 1 KiB wave-loads that cover TA rows of up to 8*CPL floats
   typedef float nat4 __attribute__((ext_vector_type(4)));
   extern __shared__ __align__(16) char lds_raw[];
   const int lane = threadIdx.x;
@@ -109,13 +118,13 @@ __global__ __launch_bounds__(YP_WAVE) void score_filter_kernel(const ScoreFilter
   float* const tile = reinterpret_cast<float*>(lds_raw);
   int2* const s_list = reinterpret_cast<int2*>(lds_raw + p.bufb);   // (tile-local anchor, row max) of anchors past phase 1
   u64* const s_key = reinterpret_cast<u64*>(s_list + YP_WAVE);      // keys waiting to be written out
-  const int grp = lane >> 4, j = lane & 15;
-  int cidx[CPL];     // this lane's classes j, j+16, ... (clamped) and whether they exist
+  const int grp = lane >> 3, j = lane & 7;
+  int cidx[CPL];     // this lane's classes j, j+8, ... (clamped) and whether they exist
   float okf[CPL];
 #pragma unroll
   for (int i = 0; i < CPL; ++i) {
-    cidx[i] = min(j + 16 * i, C - 1);
-    okf[i] = (j + 16 * i) < C ? 1.0f : 0.0f;
+    cidx[i] = min(j + 8 * i, C - 1);
+    okf[i] = (j + 8 * i) < C ? 1.0f : 0.0f;
   }
   const u64 lt_mask = (1ull << lane) - 1ull;
   const int lane16 = lane * 16;
@@ -211,7 +220,7 @@ __global__ __launch_bounds__(YP_WAVE) void score_filter_kernel(const ScoreFilter
       // Straight-line on purpose: the CPL logits of a lane are fetched together, the CPL exponentials
       // are independent chains the scheduler can interleave, invalid class slots are multiplied by 0
       // instead of being branched around.
-      for (int t0 = 0; t0 < npass; t0 += 4) {
+      for (int t0 = 0; t0 < npass; t0 += 8) {
         const int slot = t0 + grp;
         const bool act = slot < npass;
         const int2 ent = s_list[min(slot, npass - 1)];
@@ -223,14 +232,14 @@ __global__ __launch_bounds__(YP_WAVE) void score_filter_kernel(const ScoreFilter
         for (int i = 0; i < CPL; ++i) e[i] = r[cidx[i]];
 #pragma unroll
         for (int i = 0; i < CPL; ++i) e[i] = yp_exp_le0(e[i] - ma) * okf[i];   // x <= row max; 0 for c >= C
-        float s = e[0];                                                        // s_j = e_j + e_{j+16} + ...
+        float s_lo = e[0], s_hi = CPL > 1 ? e[1] : 0.0f;                       // s_j = e_j + e_{j+16} + ..., s_{j+8} = e_{j+8} + e_{j+24} + ...
 #pragma unroll
-        for (int i = 1; i < CPL; ++i) s = s + e[i];
+        for (int i = 2; i < CPL; ++i) { if (i & 1) s_hi = s_hi + e[i]; else s_lo = s_lo + e[i]; }
         float em = j > 0 ? e[0] : 0.0f;                        // class 0 is background (detection.py:59)
 #pragma unroll
         for (int i = 1; i < CPL; ++i) em = max_nonneg(em, e[i]);   // e >= 0: integer max on the bit patterns
-        const float S = grp16_sum(s);
-        em = grp16_max_nonneg(em);
+        const float S = grp8_sum(s_lo, s_hi);
+        em = grp8_max_nonneg(em);
         // IEEE division is monotone, so max_c fl(e_c/S) = fl(max_c e_c / S)              (detection.py:62)
         const float pmax = em / S;
         const bool surv = act && (pmax > p.conf);                                      // detection.py:73
@@ -247,22 +256,22 @@ __global__ __launch_bounds__(YP_WAVE) void score_filter_kernel(const ScoreFilter
           for (int i = 0; i < CPL; ++i) {
             const bool hit = (e[i] >= ethr) && (i > 0 || j > 0);
             cnt += hit ? 1 : 0;
-            cmin = hit ? min(cmin, j + 16 * i) : cmin;
+            cmin = hit ? min(cmin, j + 8 * i) : cmin;
           }
-          cnt = grp16_sum_i(cnt);
-          int arg = grp16_min(cmin);
+          cnt = grp8_sum_i(cnt);
+          int arg = grp8_min(cmin);
           if (__ballot(surv && cnt > 1)) {   // rare: several classes within 2^-21 -> exact test
             int a2 = 0x7fffffff;
 #pragma unroll
             for (int i = 0; i < CPL; ++i) {
               const bool hit = (e[i] >= ethr) && (i > 0 || j > 0);
-              if (hit && (e[i] / S == pmax)) a2 = min(a2, j + 16 * i);
+              if (hit && (e[i] / S == pmax)) a2 = min(a2, j + 8 * i);
             }
-            a2 = grp16_min(a2);
+            a2 = grp8_min(a2);
             if (cnt > 1) arg = a2;
           }
           if (lead) s_key[nbuf + __popcll(bl & lt_mask)] = yp_seg_key(pmax, a0 + al, arg);
-          nbuf += __popcll(bl);   // <= 4 per round, <= 32 per tile: flushed between tiles
+          nbuf += __popcll(bl);   // <= 8 per round, <= 32 per tile: flushed between tiles
         } else {
           // per-class candidates: every (anchor, class) with p > conf                 (detection.py:233)
           const float elo = S * p.conf_lo;
@@ -272,7 +281,7 @@ __global__ __launch_bounds__(YP_WAVE) void score_filter_kernel(const ScoreFilter
           for (int i = CPL - 1; i >= 0; --i) {
             const bool hit = surv && (e[i] >= elo) && (i > 0 || j > 0);
             nhit += hit ? 1 : 0;
-            csel = hit ? j + 16 * i : csel;
+            csel = hit ? j + 8 * i : csel;
             esel = hit ? e[i] : esel;
           }
           if (__ballot(nhit > 1) == 0) {
@@ -294,7 +303,7 @@ __global__ __launch_bounds__(YP_WAVE) void score_filter_kernel(const ScoreFilter
               const u64 bm = __ballot(has);
               if (bm) {
                 if (nbuf + __popcll(bm) > YP_SF_KCAP) flush();   // wave-uniform, rare
-                if (has) s_key[nbuf + __popcll(bm & lt_mask)] = yp_seg_key(pc, a0 + al, j + 16 * i);
+                if (has) s_key[nbuf + __popcll(bm & lt_mask)] = yp_seg_key(pc, a0 + al, j + 8 * i);
                 nbuf += __popcll(bm);
               }
             }
@@ -322,17 +331,19 @@ template <int MODE>
 static const void* kernel_for(int cpl) {
 #define YP_SF_CASE(N) case N: return reinterpret_cast<const void*>(&score_filter_kernel<MODE, N>);
   switch (cpl) {
-    YP_SF_CASE(1) YP_SF_CASE(2) YP_SF_CASE(3) YP_SF_CASE(4) YP_SF_CASE(5) YP_SF_CASE(6)
-    YP_SF_CASE(8) YP_SF_CASE(12) YP_SF_CASE(16)
+    YP_SF_CASE(2) YP_SF_CASE(4) YP_SF_CASE(6) YP_SF_CASE(8) YP_SF_CASE(10) YP_SF_CASE(11) YP_SF_CASE(12)
+    YP_SF_CASE(14) YP_SF_CASE(16) YP_SF_CASE(20) YP_SF_CASE(24) YP_SF_CASE(32)
   }
 #undef YP_SF_CASE
   return nullptr;
 }
 
+// classes per lane in phase 2 (8 lanes per anchor), rounded up to an instantiated value
 static int classes_per_lane(int C) {
-  int cpl = (C + 15) / 16;
-  if (cpl == 7) cpl = 8; else if (cpl > 8 && cpl <= 12) cpl = 12; else if (cpl > 12) cpl = 16;
-  return cpl;
+  static const int avail[] = {2, 4, 6, 8, 10, 11, 12, 14, 16, 20, 24, 32};
+  const int need = (C + 7) / 8;
+  for (int v : avail) if (v >= need) return v;
+  return 32;
 }
 
 static size_t lds_bytes(const yp_handle* h) { return (size_t)h->sf_bufb + YP_WAVE * sizeof(int2) + YP_SF_KCAP * sizeof(u64); }
