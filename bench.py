@@ -73,11 +73,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (the hot path has no CPU fallback)")
+    # Rehearsal knobs for a one-GPU box (the driver's multi-GPU runs use neither): all ranks on one
+    # device, and gloo instead of RCCL (RCCL refuses two ranks on one GPU).
+    backend = os.environ.get("YP_BENCH_BACKEND", "nccl")
+    if os.environ.get("YP_BENCH_ONE_DEVICE"):
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from yolact_amd import PostConfig, PostProcessor, synth
 
@@ -133,7 +141,7 @@ def main():
     t1 = time.perf_counter()
     elapsed = t1 - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
