@@ -57,6 +57,9 @@ def main():
     ap.add_argument("--batch", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=16)
+    ap.add_argument("--reference-layout", action="store_true",
+                    help="the reference as shipped (detection.py:21-22,83,181): cross-class NMS, top_k 15, "
+                         "300 zero-padded rows per image")
     ap.add_argument("--inflight", type=int, default=1,
                     help="batches in flight: N handles on N HIP streams taking the steps in turn")
     ap.add_argument("--timed-events", type=int, default=0,
@@ -95,8 +98,12 @@ def main():
     A, C = net["pred_cls"].shape[1:]
     ph, pw = net["proto_out"].shape[1:3]
     P, K = ph * pw, 32
+    top_k, max_dets, zero_pad = cfg.top_k, cfg.max_dets, False
+    if args.reference_layout:
+        args.nms_mode, top_k, max_dets, zero_pad = "cc", 15, 300, True
     pc = PostConfig(A, C, ph, pw, cfg.img_h, cfg.img_w, conf_thresh=cfg.conf_thresh, nms_thresh=cfg.nms_thresh,
-                    nms_mode=args.nms_mode, top_k=cfg.top_k, max_dets=cfg.max_dets, max_batch=B, device_id=local_rank)
+                    nms_mode=args.nms_mode, top_k=top_k, max_dets=max_dets, zero_pad_masks=zero_pad, max_batch=B,
+                    device_id=local_rank)
     pp = PostProcessor(pc)
     d = {k: torch.from_numpy(v).to(dev) for k, v in net.items()}
     out = pp.alloc_outputs(B)
@@ -162,8 +169,9 @@ def main():
 
     S = pp.last_survivors(B)
     N = out["num_detections"].cpu().numpy()
-    total_bytes = algorithmic_bytes(cfg, A, C, P, K, S, N)
-    kb = kernel_bytes(A, C, P, K, S, N, args.nms_mode)
+    rows = np.full_like(N, max_dets) if zero_pad else N     # mask rows actually written (tf.zeros rows included)
+    total_bytes = algorithmic_bytes(cfg, A, C, P, K, S, rows)
+    kb = kernel_bytes(A, C, P, K, S, rows, args.nms_mode)
     dominant = max(kern_ms, key=lambda k: kern_ms[k])
     ach = kb[dominant] / (kern_ms[dominant] * 1e-3) / 1e9
     ms_per_step = elapsed / args.steps * 1e3
@@ -184,8 +192,8 @@ def main():
         "data": "synthetic",
         "config": {
             "workload": f"BASELINE config {args.config}: {cfg.img_h}x{cfg.img_w}, {A} anchors, {C} classes, "
-                        f"proto {ph}x{pw}x32, batch {B} per GPU, conf {cfg.conf_thresh}, top_k {cfg.top_k}, "
-                        f"max {cfg.max_dets} dets, nms_mode {args.nms_mode}",
+                        f"proto {ph}x{pw}x32, batch {B} per GPU, conf {cfg.conf_thresh}, top_k {top_k}, "
+                        f"max {max_dets} dets, nms_mode {args.nms_mode}" + (", 300 zero-padded rows" if zero_pad else ""),
             "batch_per_gpu": B, "nms_mode": args.nms_mode,
             "mean_survivors": float(np.mean(S)), "mean_dets": float(np.mean(N)),
         },

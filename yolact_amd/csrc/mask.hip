@@ -22,6 +22,7 @@ struct MaskArgs {
   float* masks;            // [B,max_dets,P]
   uint8_t* bitmaps;        // [B,max_dets,P] or null
   int P, pw, max_dets, sel_rows, zero_pad;
+  int prezeroed;           // 1: mask_zero_kernel has already zero-filled every row this kernel would
   float mask_threshold;
 };
 
@@ -128,7 +129,9 @@ __global__ __launch_bounds__(YP_MASK_BLOCK) void mask_assemble_kernel(const Mask
   const uint32_t rstride = (uint32_t)p.P * 4u;
   const bool plain = !NT_STORE && brow == nullptr;
   const bool wide = plain && (p.P & 3) == 0 && ((uintptr_t)p.masks & 15u) == 0;
-  if (wide) {
+  if (p.prezeroed) {
+    // nothing: the rows are zero already and only the detections that touch this wave are rewritten
+  } else if (wide) {
     // the workgroup's 256 pixels of a row are 1 KiB: one 16-byte store per lane zeroes a whole row
     // segment (eight full lines), wave w taking rows w, w+4, ...  The rows are then rewritten by the
     // waves that own their pixels, so these stores must have completed first.
@@ -136,7 +139,8 @@ __global__ __launch_bounds__(YP_MASK_BLOCK) void mask_assemble_kernel(const Mask
     if (lane < (npx >> 2)) {
       uint32_t vo = (uint32_t)lane * 16u + (uint32_t)wv * rstride;
       const nat4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
-      for (int n = wv; n < N; n += YP_MASK_BLOCK / 64, vo += (YP_MASK_BLOCK / 64) * rstride)
+      const int nz = p.zero_pad ? p.max_dets : N;   // tf.zeros rows of detection.py:68 included
+      for (int n = wv; n < nz; n += YP_MASK_BLOCK / 64, vo += (YP_MASK_BLOCK / 64) * rstride)
         asm volatile("global_store_dwordx4 %0, %1, %2" ::"v"(vo), "v"(zero4), "s"(orow) : "memory");
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -188,12 +192,42 @@ __global__ __launch_bounds__(YP_MASK_BLOCK) void mask_assemble_kernel(const Mask
   }
   float* const out_img = p.masks + (size_t)b * p.max_dets * p.P;
   uint8_t* const bit_img = p.bitmaps ? p.bitmaps + (size_t)b * p.max_dets * p.P : nullptr;
-  if (p.zero_pad && live) {   // tf.zeros rows of detection.py:68
+  if (p.zero_pad && live && !wide && !p.prezeroed) {   // tf.zeros rows of detection.py:68 (the wide zero pass has written them already)
     for (int n = N; n < p.max_dets; ++n) {
       const size_t o = (size_t)n * p.P + pix;
       out_img[o] = 0.0f;
       if (bit_img) bit_img[o] = 0;
     }
+  }
+}
+
+// Zero-fill of the mask rows as one linear stream per image (rows 0 .. nz-1 of an image are
+// contiguous): the form in which HBM takes writes fastest (a plain fill reaches 6.8 TB/s on 0.7-1.3 GB,
+// the 1 KiB pieces of the fused zero pass ~4 TB/s once the output no longer fits the Infinity Cache).
+// ESIZE = bytes per element (4: float masks, 1: bitmaps).  Workgroup (c, b) fills bytes
+// [c*16 KiB, (c+1)*16 KiB) of image b's region.
+template <int ESIZE>
+__global__ __launch_bounds__(256) void mask_zero_kernel(void* out, const int32_t* num_det, long long P, int max_dets, int sel_rows,
+                                                        int zero_pad) {
+  const int b = blockIdx.y;
+  const int nz = zero_pad ? max_dets : min(num_det[b], sel_rows);
+  const long long len = (long long)nz * P * ESIZE;                 // bytes to clear
+  char* const base = reinterpret_cast<char*>(out) + (long long)b * max_dets * P * ESIZE;
+  const long long lo = (long long)blockIdx.x * 16384;
+  if (lo >= len) return;
+  const long long hi = min(lo + 16384, len);
+  if ((((uintptr_t)base) & 15u) == 0) {
+    typedef float nat4 __attribute__((ext_vector_type(4)));
+    const nat4 z = {0.0f, 0.0f, 0.0f, 0.0f};
+    const long long hi16 = hi & ~15ll;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long long o = lo + ((long long)u * 256 + threadIdx.x) * 16;
+      if (o < hi16) *reinterpret_cast<nat4*>(base + o) = z;
+    }
+    for (long long o = hi16 + threadIdx.x; o < hi; o += 256) base[o] = 0;
+  } else {
+    for (long long o = lo + threadIdx.x; o < hi; o += 256) base[o] = 0;
   }
 }
 
@@ -215,7 +249,21 @@ hipError_t yp_launch_mask_assemble(const yp_handle* h, int batch, const float* p
   // where fewer concurrent write streams keep more DRAM pages open: 2 workgroups per CU measured
   // best (config 5: 499 -> 442 us).
   const size_t out_bytes = (size_t)batch * a.max_dets * a.P * sizeof(float);
-  size_t pad = out_bytes > ((size_t)256 << 20) ? 66000 : 0;
+  const bool big = out_bytes > ((size_t)256 << 20);
+  // Outputs beyond the Infinity Cache: the zeros go out first, as a linear fill; mask_assemble then
+  // only writes the rows that detections touch.  (Inside the cache the fused zero pass is as fast
+  // and saves a launch.)
+  a.prezeroed = big ? 1 : 0;
+  if (const char* ev = getenv("YP_MASK_PREZERO")) a.prezeroed = atoi(ev) != 0;   // tuning knob
+  if (a.prezeroed) {
+    const long long region = (long long)a.max_dets * a.P;
+    hipLaunchKernelGGL((mask_zero_kernel<4>), dim3((unsigned)((region * 4 + 16383) / 16384), batch), dim3(256), 0, st,
+                       (void*)det_masks, num_det, (long long)a.P, a.max_dets, a.sel_rows, a.zero_pad);
+    if (det_bitmaps)
+      hipLaunchKernelGGL((mask_zero_kernel<1>), dim3((unsigned)((region + 16383) / 16384), batch), dim3(256), 0, st,
+                         (void*)det_bitmaps, num_det, (long long)a.P, a.max_dets, a.sel_rows, a.zero_pad);
+  }
+  size_t pad = (big && !a.prezeroed) ? 66000 : 0;
   if (const char* ev = getenv("YP_MASK_LDS_PAD")) pad = (size_t)atoi(ev);   // tuning knob
   if (nt) hipLaunchKernelGGL((mask_assemble_kernel<true>), grid, dim3(YP_MASK_BLOCK), pad, st, a, bpi, batch);
   else hipLaunchKernelGGL((mask_assemble_kernel<false>), grid, dim3(YP_MASK_BLOCK), pad, st, a, bpi, batch);
