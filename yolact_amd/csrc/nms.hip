@@ -519,6 +519,8 @@ __global__ __launch_bounds__(THREADS) void cc_nms_kernel(const NmsArgs p) {
   __shared__ int s_wave_cnt[YP_SORT_MAX / YP_WAVE];
   const int t = threadIdx.x;
   const int b = blockIdx.x;
+  STAMP_INIT(0, b);
+  STAMP(0);
   const int32_t* counts = p.seg_count + (size_t)b * p.parts;
   int part = 0;
   for (int i = t; i < p.parts; i += THREADS) part += counts[i];
@@ -527,8 +529,14 @@ __global__ __launch_bounds__(THREADS) void cc_nms_kernel(const NmsArgs p) {
     finish_image<THREADS>(p, b, 0, 0);
     return;
   }
+  STAMP(1);
   const PartSrc src{p.cand + (size_t)b * p.parts * p.cap_item, counts, p.parts, p.cap_item, 0, 0, 0};
+#ifdef YP_STAMPS
+  const int k = select_topk_sorted<THREADS>(src, n, p.top_k, sh, stage, dbg_);
+#else
   const int k = select_topk_sorted<THREADS>(src, n, p.top_k, sh, stage);       // detection.py:186
+#endif
+  STAMP(2);
   float4 mybox = make_float4(0.f, 0.f, 0.f, 0.f);
   float4 cf[YP_MASK_DIM / 4];
   int anchor = 0;
@@ -543,14 +551,18 @@ __global__ __launch_bounds__(THREADS) void cc_nms_kernel(const NmsArgs p) {
     }
   }
   __syncthreads();
+  STAMP(3);
   int pos, total;
   const bool keep = fast_nms_keep<THREADS>(sbox, ssup, s_wave_cnt, k, p.nms_thresh, pos, total);
+  STAMP(4);
   const int nk = min(total, p.max_dets);
   if (keep && pos < nk) {
     const u64 key = sh.key[t];
     emit_row(p, b, pos, yp_key_score(key), yp_seg_key_class(key), anchor, mybox, cf);   // detection.py:204-207
   }
+  STAMP(5);
   finish_image<THREADS>(p, b, nk, n);
+  STAMP(6);
 }
 
 // ---- per-class mode -------------------------------------------------------------------------
