@@ -293,3 +293,25 @@ def test_device_priors_bit_exact(torch_cuda, hw):
     assert np.array_equal(host.view(np.uint32), ref.view(np.uint32))
     assert anchors.make_priors_device(H, W, feature_maps=fm, aspect_ratios=ratios, scales=scales).data_ptr() == \
         anchors.make_priors_device(H, W, feature_maps=fm, aspect_ratios=ratios, scales=scales).data_ptr()   # cached
+
+
+def test_randomized_small_shapes(torch_cuda):
+    """Forty random small problems (anchor counts that are not multiples of 4 or 32, 2..40 classes, odd
+    proto sizes, thresholds from permissive to strict, both modes): every output bit-identical."""
+    from yolact_amd import synth
+    rng = np.random.default_rng(2024)
+    for case in range(40):
+        fh, fw = int(rng.integers(1, 9)), int(rng.integers(1, 9))
+        fmaps = ((fh, fw),) if rng.random() < 0.5 else ((fh, fw), (max(1, fh // 2), max(1, fw // 2)))
+        C = int(rng.integers(2, 41))
+        proto_hw = (int(rng.integers(3, 20)), int(rng.integers(3, 20)))
+        batch = int(rng.integers(1, 5))
+        mode = "cc" if rng.random() < 0.5 else "per_class"
+        top_k = int(rng.integers(1, 60))
+        max_dets = int(rng.integers(1, 50))
+        conf = float(rng.choice([0.0, 0.01, 0.05, 0.3, 0.9]))
+        nms = float(rng.choice([0.05, 0.3, 0.5, 0.95]))
+        net, shp = synth.make_toy(1000 + case, batch=batch, fmaps=fmaps, num_classes=C, proto_hw=proto_hw,
+                                  p_fg=float(rng.choice([0.0, 0.1, 0.6])), scales=(12, 24)[:len(fmaps)])
+        label = f"rand{case}: A={net['pred_cls'].shape[1]} C={C} P={proto_hw} B={batch} {mode} k={top_k} md={max_dets} conf={conf} nms={nms}"
+        check_vs_c_oracle(torch_cuda, net, shp, mode=mode, top_k=top_k, max_dets=max_dets, conf=conf, nms=nms, label=label)

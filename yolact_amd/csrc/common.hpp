@@ -152,6 +152,10 @@ static inline void yp_plan_items(const yp_handle* h, int batch, int* parts, long
   const int resident = h->num_cus * h->sf_waves_per_cu;
   int pt = batch > 0 ? resident / batch : 1;
   pt = pt < 1 ? 1 : (pt > h->ntiles ? h->ntiles : pt);
+  // the longest item sets the kernel's length: keep its tile count, but use only as many items as
+  // that needs, so that (nearly) all items are equally long (602 tiles: 86 x 7 instead of 96 x 6..7)
+  const int longest = (h->ntiles + pt - 1) / pt;
+  pt = (h->ntiles + longest - 1) / longest;
   *parts = pt;
   *cap_item = (long long)((h->ntiles + pt - 1) / pt) * YP_SF_TA * h->keys_per_anchor;
 }
