@@ -7,9 +7,10 @@
 // HBM-bound by the N*4*P bytes of masks it writes per image (K=32 gives ~12 flop/byte, below the
 // ~25 flop/byte balance of 157 TFLOP/s fp32 over ~6.3 TB/s).  A lane owns one proto pixel and
 // keeps its 32 prototype values in VGPRs for the whole kernel, so the prototypes are read from
-// HBM exactly once; the coefficients and crop edges of detection n are wave-uniform and come in
-// through scalar loads.  The dot product is a K-ordered fma chain (YP-MATH) and is skipped for
-// waves whose 64 pixels lie entirely outside detection n's crop box - those only store zeros.
+// HBM exactly once; the coefficients and crop edges of a detection are wave-uniform and come in
+// through scalar loads.  The dot product is a K-ordered fma chain (YP-MATH) and is only evaluated
+// by waves whose 64 pixels can lie inside the detection's crop box; everything else is zeros, written
+// in bulk (pass Z below, or mask_zero_kernel for outputs beyond the Infinity Cache).
 // Output is written [N][P] (pixel-contiguous), which is the reference's final layout.
 #include <stdlib.h>
 #include "common.hpp"
@@ -34,8 +35,9 @@ struct MaskArgs {
 //      coalesced NON-TEMPORAL 16-byte loads (read once, by nobody else: they must not displace the
 //      output lines that live in L2 / Infinity Cache) and transposed through LDS, so that every lane
 //      ends up with its pixel's 32 values in VGPRs;
-//   2. loop over the image's detections: crop test, K-ordered fma chain + sigmoid for waves that
-//      touch the crop box, one coalesced 256-byte store per wave and detection.
+//   2. pass Z: every row of the workgroup's pixels gets zeros (16-byte stores, 1 KiB per
+//      wave-instruction); pass R: the detections whose crop box can touch the wave's pixels (one bit
+//      each, found with ctz) get the K-ordered fma chain + sigmoid + crop and are stored again.
 // Workgroups of one image are placed on one XCD (the dispatcher deals consecutive workgroup ids
 // round-robin over the 8 XCDs), so the partial cache lines at workgroup borders (mask rows are
 // only 16-byte aligned: P*4 bytes is not a multiple of 128) merge in a single L2.
@@ -84,9 +86,7 @@ __global__ __launch_bounds__(YP_MASK_BLOCK) void mask_assemble_kernel(const Mask
   const float frow = live ? (float)r : -1.0f;                  // tf.range(..., dtype=float32), utils/utils.py:119-120
   const float fcol = live ? (float)(pix - r * p.pw) : -1.0f;
 
-  // Row addresses are a wave-uniform base (SGPRs, advanced by scalar adds) plus the lane's constant
-  // offset: a row of zeros then costs one store and no vector arithmetic at all - the kernel is bound
-  // by instruction issue as much as by HBM.
+  // Row addresses are a wave-uniform base (SGPRs) plus a 32-bit lane offset (global_store saddr form)
   float* orow = p.masks + ((size_t)b * p.max_dets) * p.P + base_pix;
   uint8_t* brow = p.bitmaps ? p.bitmaps + ((size_t)b * p.max_dets) * p.P + base_pix : nullptr;
   typedef const __attribute__((address_space(4))) float cfloat;
@@ -96,10 +96,8 @@ __global__ __launch_bounds__(YP_MASK_BLOCK) void mask_assemble_kernel(const Mask
   // Which detections can touch this wave's 64 pixels at all?  Lane l tests detection g*64+l against
   // a bounding range of the wave's pixels (a superset test: the per-pixel compares below decide the
   // values); the ballots give a bit per detection.  Rows of all other detections are plain zeros.
-  // The kernel is bound by instruction issue as much as by HBM, so everything wave-uniform is kept
-  // in SGPRs on purpose (readfirstlane where the compiler cannot prove it): the bit test is scalar,
-  // and a row's address is a scalar base plus the lane's constant byte offset - a row of zeros
-  // costs one store and no vector arithmetic.
+  // Everything wave-uniform is kept in SGPRs on purpose (readfirstlane where the compiler cannot
+  // prove it), so that walking the bits is scalar work.
   const int lane = t & 63;
   const int w0 = base_pix + __builtin_amdgcn_readfirstlane(t >> 6) * 64, w1 = min(w0 + 63, p.P - 1);
   u64 rel[YP_SORT_MAX / 64] = {0ull, 0ull, 0ull, 0ull};
