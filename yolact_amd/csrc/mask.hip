@@ -147,7 +147,6 @@ __global__ __launch_bounds__(YP_MASK_BLOCK) void mask_assemble_kernel(const Mask
     if (plain) {
       uint32_t vo = voff;
       const float zero = 0.0f;
-#pragma unroll 4
       for (int n = 0; n < N; ++n, vo += rstride)
         asm volatile("global_store_dword %0, %1, %2" ::"v"(vo), "v"(zero), "s"(orow) : "memory");
     } else {
