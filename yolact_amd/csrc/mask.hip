@@ -121,8 +121,8 @@ __global__ __launch_bounds__(YP_MASK_BLOCK) void mask_assemble_kernel(const Mask
   // The CU's scalar unit is shared by all its waves, and a loop over every detection with a test and
   // a branch per row is bound by it (measured: ~36 of 62 us with no memory traffic at all).  So:
   //   pass Z  every row gets zeros: one store + one vector add per row, nothing scalar but the loop
-  //   pass R  only the rows whose bit is set (found with ctz) are computed and stored again; stores
-  //           of one wave to one address stay in order
+  //   pass R  only the rows whose bit is set (found with ctz) are computed and stored again, after
+  //           the zeros have been acknowledged (vmcnt(0), plus a barrier where another wave wrote them)
   const uint32_t voff = (uint32_t)t * 4u;
   const uint32_t rstride = (uint32_t)p.P * 4u;
   const bool plain = !NT_STORE && brow == nullptr;
@@ -156,6 +156,8 @@ __global__ __launch_bounds__(YP_MASK_BLOCK) void mask_assemble_kernel(const Mask
       }
     }
   }
+  // per-wave zero pass: this wave rewrites its own addresses below; its zeros are acknowledged first
+  if (!p.prezeroed && !wide) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
   for (int g = 0; g < YP_SORT_MAX / 64; ++g) {
     u64 w = g * 64 < N ? rel[g] : 0ull;        // wave-uniform
