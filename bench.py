@@ -222,7 +222,9 @@ def main():
     except Exception:
         pass
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(net, shp, cfg, args)
+        result["cpu_baseline"] = cpu_baseline(net, shp, cfg, args, top_k, max_dets)
+        result["parity"] = parity_report(net, shp, cfg, args, top_k, max_dets, {k: v.cpu().numpy() for k, v in out.items()
+                                                                                  if k != "detection_masks"})
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:
@@ -230,15 +232,48 @@ def main():
         dist.destroy_process_group()
 
 
-def cpu_baseline(net, shp, cfg, args):
+def parity_report(net, shp, cfg, args, top_k, max_dets, got):
+    """Part of the cpu_baseline leg (the oracle as the checker, never the thing measured): the timed
+    batch's kept detections against (i) the C oracle, which shares the kernels' arithmetic contract
+    - expected bit-exact - and (ii) the numpy oracle with libm exp / numpy reductions, the stand-in
+    for the reference's TF CPU arithmetic (north_star: >= 95 % kept-index agreement)."""
+    from oracle import c_oracle, detect_oracle
+    kw = dict(conf_thresh=cfg.conf_thresh, nms_thresh=cfg.nms_thresh, top_k=top_k, nms_mode=args.nms_mode, max_dets=max_dets)
+    nb = min(16, net["pred_cls"].shape[0])
+    sub = {k: (v[:nb] if k != "priors" else v) for k, v in net.items()}
+    ref_c = c_oracle.detect(sub, shp, nthreads=max(1, min(args.cpu_threads, os.cpu_count() or 1)), **kw)
+    ref_n = detect_oracle.detect(sub, shp, max_output_size=max_dets, **kw)
+
+    def rates(ref):
+        rows_same = rows_tot = sets = 0
+        for b in range(nb):
+            n, m = int(ref["num_detections"][b]), int(got["num_detections"][b])
+            a = list(zip(got["detection_anchor_indices"][b, :m].tolist(), got["detection_classes"][b, :m].tolist()))
+            d = list(zip(ref["detection_anchor_indices"][b, :n].tolist(), ref["detection_classes"][b, :n].tolist()))
+            rows_same += sum(x == y for x, y in zip(a, d)); rows_tot += max(n, m); sets += set(a) == set(d)
+        return round(rows_same / max(1, rows_tot), 4), round(sets / nb, 4)
+
+    rc, rn = rates(ref_c), rates(ref_n)
+    rows = min(got["detection_scores"].shape[1], ref_c["detection_scores"].shape[1])
+    return {
+        "images": nb,
+        "vs_c_oracle_same_contract": {"kept_index_agreement": rc[0], "kept_set_agreement": rc[1],
+                                      "scores_bit_exact": bool(np.array_equal(got["detection_scores"][:nb, :rows], ref_c["detection_scores"][:, :rows])),
+                                      "boxes_bit_exact": bool(np.array_equal(got["detection_boxes"][:nb, :rows], ref_c["detection_boxes"][:, :rows]))},
+        "vs_numpy_oracle_libm": {"kept_index_agreement": rn[0], "kept_set_agreement": rn[1],
+                                 "note": "row-wise; rows differ only where two scores are within an ulp"},
+    }
+
+
+def cpu_baseline(net, shp, cfg, args, top_k, max_dets):
     """The oracle's C port (oracle/detect_oracle.c) timed on this host: the checker, timed as a
     baseline - never the thing shipped.  The reference itself (TF2) cannot run here."""
     from oracle import c_oracle
     c_oracle.lib()
     threads = max(1, min(args.cpu_threads, os.cpu_count() or 1))
     B = net["pred_cls"].shape[0]
-    kw = dict(conf_thresh=cfg.conf_thresh, nms_thresh=cfg.nms_thresh, top_k=cfg.top_k, nms_mode=args.nms_mode,
-              max_dets=cfg.max_dets)
+    kw = dict(conf_thresh=cfg.conf_thresh, nms_thresh=cfg.nms_thresh, top_k=top_k, nms_mode=args.nms_mode,
+              max_dets=max_dets)
     n1 = min(4, B)
     sub = {k: (v[:n1] if k != "priors" else v) for k, v in net.items()}
     t0 = time.perf_counter()

@@ -315,3 +315,25 @@ def test_randomized_small_shapes(torch_cuda):
                                   p_fg=float(rng.choice([0.0, 0.1, 0.6])), scales=(12, 24)[:len(fmaps)])
         label = f"rand{case}: A={net['pred_cls'].shape[1]} C={C} P={proto_hw} B={batch} {mode} k={top_k} md={max_dets} conf={conf} nms={nms}"
         check_vs_c_oracle(torch_cuda, net, shp, mode=mode, top_k=top_k, max_dets=max_dets, conf=conf, nms=nms, label=label)
+
+
+def test_kept_index_agreement_vs_independent_arithmetic(torch_cuda):
+    """north_star target: >= 95 % kept-index agreement with the reference arithmetic on unfiltered seeds.
+    The stand-in for the reference's TF CPU arithmetic is the numpy oracle (libm exp, numpy
+    reductions, BLAS matmul) - independent of the YP-MATH contract the kernels share with the C
+    oracle.  Per output row and per kept set; rows of images that agree are within 1e-5."""
+    from oracle import detect_oracle as po
+    from tests.util import kept_index_agreement
+    from yolact_amd import synth
+    cfg = synth.CONFIGS[2]
+    net, shp = synth.make_batch(cfg, batch=32, first_image=200)
+    for mode, top_k, md in (("per_class", 200, 100), ("cc", 15, 15)):
+        got = run_gpu(torch_cuda, net, shp, mode=mode, top_k=top_k, max_dets=md, conf=cfg.conf_thresh)
+        ref = po.detect(net, shp, conf_thresh=cfg.conf_thresh, top_k=top_k, nms_mode=mode, max_output_size=md, max_dets=md)
+        rate = kept_index_agreement(got, ref)
+        print(f"kept-index agreement {mode}: {rate}")
+        assert rate["per_detection"] >= 0.95 and rate["kept_set"] >= 0.95, (mode, rate)
+        same = [b for b in range(32) if np.array_equal(got["detection_anchor_indices"][b], ref["detection_anchor_indices"][b])]
+        assert len(same) > 0
+        assert np.abs(got["detection_scores"][same] - ref["detection_scores"][same]).max() <= TOL
+        assert np.abs(got["detection_boxes"][same] - ref["detection_boxes"][same]).max() <= TOL
