@@ -337,3 +337,19 @@ def test_kept_index_agreement_vs_independent_arithmetic(torch_cuda):
         assert len(same) > 0
         assert np.abs(got["detection_scores"][same] - ref["detection_scores"][same]).max() <= TOL
         assert np.abs(got["detection_boxes"][same] - ref["detection_boxes"][same]).max() <= TOL
+
+
+def test_exact_order_vs_independent_arithmetic_on_unsaturated_scores(torch_cuda):
+    """Deterministic setting: scores spread over 0.2-0.99, no ulp-level near-ties.  Kept
+    indices, classes and NMS ordering must then be identical to the independent numpy/libm oracle on
+    every image, boxes / scores / masks within 1e-5 (the north_star bar, full batch of 32)."""
+    from oracle import detect_oracle as po
+    from tests.util import kept_index_agreement
+    from yolact_amd import synth
+    cfg = synth.CONFIGS[2]
+    net, shp = synth.make_batch(cfg, batch=32, first_image=300, mode="planted_soft")
+    for mode, top_k, md in (("per_class", 200, 100), ("cc", 15, 15)):
+        got = run_gpu(torch_cuda, net, shp, mode=mode, top_k=top_k, max_dets=md, conf=cfg.conf_thresh)
+        ref = po.detect(net, shp, conf_thresh=cfg.conf_thresh, top_k=top_k, nms_mode=mode, max_output_size=md, max_dets=md)
+        assert kept_index_agreement(got, ref)["exact_order"] == 1.0, mode
+        compare(got, ref, exact_values=False, atol=TOL, label=f"soft-{mode}")

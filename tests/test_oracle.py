@@ -207,3 +207,20 @@ def test_kept_index_agreement_between_the_two_arithmetics():
         rate = kept_index_agreement(c, r)
         assert rate["per_detection"] >= 0.95 and rate["kept_set"] >= 0.95, (mode, rate)
         assert np.abs(np.sort(c["detection_scores"], axis=1) - np.sort(r["detection_scores"], axis=1)).max() <= 1e-5
+
+
+def test_exact_agreement_on_unsaturated_scores():
+    """The "deterministic" setting of SURVEY.md 8d: with foreground probabilities spread over 0.2-0.99
+    instead of saturating at 0.999 (synth mode "planted_soft"), no two scores are an ulp apart, and the
+    two arithmetics keep the same anchors, classes and ORDER on every image."""
+    from tests.util import kept_index_agreement
+    from yolact_amd import synth
+    from oracle import c_oracle as co, detect_oracle as po
+    cfg = synth.CONFIGS[2]
+    net, shp = synth.make_batch(cfg, batch=16, first_image=300, mode="planted_soft")
+    for mode, top_k, md in (("per_class", 200, 100), ("cc", 200, 100), ("cc", 15, 15)):
+        c = co.detect(net, shp, conf_thresh=cfg.conf_thresh, top_k=top_k, nms_mode=mode, max_dets=md, nthreads=8)
+        r = po.detect(net, shp, conf_thresh=cfg.conf_thresh, top_k=top_k, nms_mode=mode, max_output_size=md, max_dets=md)
+        assert kept_index_agreement(c, r) == {"per_detection": 1.0, "kept_set": 1.0, "exact_order": 1.0}, mode
+        assert np.abs(c["detection_scores"] - r["detection_scores"]).max() <= 1e-5
+        assert np.abs(c["detection_boxes"] - r["detection_boxes"]).max() <= 1e-5

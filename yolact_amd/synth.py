@@ -30,7 +30,7 @@ class SynthConfig:
     top_k: int = 200
     max_dets: int = 100
     p_fg: float = 0.03
-    mode: str = "planted"        # "planted" | "random_init" | "saturated"
+    mode: str = "planted"        # "planted" | "planted_soft" | "random_init" | "saturated"
 
     @property
     def proto_hw(self):
@@ -70,7 +70,10 @@ def make_image(cfg: SynthConfig, image_index: int, priors: np.ndarray | None = N
             planted = rng.random(A) < cfg.p_fg
             idx = np.nonzero(planted)[0]
             fg = rng.integers(0, C - 1, idx.shape[0])
-            boost = rng.uniform(6.0, 14.0, idx.shape[0]).astype(np.float32)
+            # "planted_soft": foreground probabilities spread over ~0.2-0.9 instead of saturating at 0.999,
+            # so that scores an ulp apart - which any two exp implementations rank differently - are rare
+            lo, hi = (4.5, 8.5) if mode == "planted_soft" else (6.0, 14.0)
+            boost = rng.uniform(lo, hi, idx.shape[0]).astype(np.float32)
             cls[idx, 1 + fg] += boost
     coef = np.tanh(rng.normal(0.0, 1.0, (A, MASK_DIM))).astype(np.float32)
     proto = np.maximum(0.0, rng.normal(0.0, 1.0, (ph, pw, MASK_DIM))).astype(np.float32)
