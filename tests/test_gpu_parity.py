@@ -353,3 +353,20 @@ def test_exact_order_vs_independent_arithmetic_on_unsaturated_scores(torch_cuda)
         ref = po.detect(net, shp, conf_thresh=cfg.conf_thresh, top_k=top_k, nms_mode=mode, max_output_size=md, max_dets=md)
         assert kept_index_agreement(got, ref)["exact_order"] == 1.0, mode
         compare(got, ref, exact_values=False, atol=TOL, label=f"soft-{mode}")
+
+
+def test_sharded_detect_matches_unsharded(torch_cuda):
+    """SURVEY.md 8e on the GPU path: the batch split into contiguous chunks, one Detect (handle, scratch)
+    per shard, results concatenated on the host in image order.  Two shards on the one device of the
+    test box stand in for two GPUs; no collective is involved."""
+    from yolact_amd import Detect, synth
+    from yolact_amd.sharding import ShardedDetect
+    net, shp = synth.make_toy(31, batch=5)
+    kw = dict(strict_reference=False, nms_mode="per_class", top_k=50, max_dets=20)
+    one = to_numpy(Detect(5, 100, 100, 0.05, 0.5, **kw)(net, shp))
+    two = ShardedDetect(5, 100, 100, 0.05, 0.5, devices=[0, 0], **kw)(net, shp)
+    two = {k: (v.numpy() if hasattr(v, "numpy") else v) for k, v in two.items()}
+    for k in ("detection_boxes", "detection_classes", "detection_scores", "detection_masks", "num_detections",
+              "detection_anchor_indices"):
+        assert np.array_equal(one[k], two[k]), k
+    assert two["num_detections"].shape == (5,)
