@@ -46,10 +46,13 @@ __global__ __launch_bounds__(YP_MASK_BLOCK) void mask_assemble_kernel(const Mask
   __shared__ float4 sproto[YP_MASK_BLOCK * YP_MASK_ROW4];
   typedef float nat4 __attribute__((ext_vector_type(4)));
   const int t = threadIdx.x;
+  // batch >= 8: image b on XCD b % 8 (see above).  Smaller batches would leave XCDs idle that way and
+  // take the plain order instead (gridDim.x == batch * blocks_per_image then).
+  const bool by_xcd = gridDim.x != (unsigned)(batch * blocks_per_image);
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-  const int b = (slot / blocks_per_image) * 8 + xcd;
+  const int b = by_xcd ? (slot / blocks_per_image) * 8 + xcd : (int)blockIdx.x / blocks_per_image;
   if (b >= batch) return;
-  const int base_pix = (slot % blocks_per_image) * YP_MASK_BLOCK;
+  const int base_pix = (by_xcd ? slot % blocks_per_image : (int)blockIdx.x % blocks_per_image) * YP_MASK_BLOCK;
   const int npx = min(YP_MASK_BLOCK, p.P - base_pix);
   const int pix = base_pix + t;
   const bool live = t < npx;
@@ -242,7 +245,7 @@ hipError_t yp_launch_mask_assemble(const yp_handle* h, int batch, const float* p
   // Infinity Cache, and a caller that reuses its output buffer overwrites them there.
   const bool nt = getenv("YP_MASK_NT") ? atoi(getenv("YP_MASK_NT")) != 0 : false;
   const int bpi = (a.P + YP_MASK_BLOCK - 1) / YP_MASK_BLOCK;
-  const dim3 grid(8 * ((batch + 7) / 8) * bpi);
+  const dim3 grid(batch >= 8 ? 8 * ((batch + 7) / 8) * bpi : batch * bpi);
   // Residency by LDS padding.  Masks that fit the 256 MiB Infinity Cache are absorbed there and the
   // kernel wants as many waves as it can get (8 workgroups per CU).  Larger outputs stream to HBM,
   // where fewer concurrent write streams keep more DRAM pages open: 2 workgroups per CU measured
