@@ -67,17 +67,6 @@ __device__ __forceinline__ float yp_sigmoid(float x) { return 1.0f / (1.0f + yp_
 
 __device__ __forceinline__ float yp_clip(float t, float lo, float hi) { return fminf(fmaxf(t, lo), hi); }
 
-// utils._iou for one pair (utils/utils.py:19-21, 40-48, 63-70); boxes are (ymin,xmin,ymax,xmax).
-__device__ __forceinline__ float yp_iou(const float4 a, const float4 b) {
-  const float area1 = (a.z - a.x) * (a.w - a.y);
-  const float area2 = (b.z - b.x) * (b.w - b.y);
-  const float ih = fmaxf(0.0f, fminf(a.z, b.z) - fmaxf(a.x, b.x));
-  const float iw = fmaxf(0.0f, fminf(a.w, b.w) - fmaxf(a.y, b.y));
-  const float inter = ih * iw;
-  const float uni = (area1 + area2) - inter;
-  return inter == 0.0f ? 0.0f : inter / uni;
-}
-
 // utils._decode for one anchor (utils/utils.py:193-213).  pr = prior (ymin,xmin,ymax,xmax) pixels,
 // of = (dx,dy,dw,dh); returns the box as (ymin,xmin,ymax,xmax) pixels.
 __device__ __forceinline__ float4 yp_decode(const float4 pr, const float4 of) {
