@@ -122,3 +122,25 @@ def test_make_priors_size_query_and_errors():
     c_bad = (ctypes.c_double * 3)(1.0, -0.5, 2.0)
     assert L.yp_make_priors(550, 550, 5, c_fm, c_sc, 3, c_bad, None, 0, 0, None) < 0
     assert L.yp_make_priors(0, 550, 5, c_fm, c_sc, 3, c_ar, None, 0, 0, None) < 0
+
+
+def test_pair_enumeration_used_by_the_nms_kernels():
+    """csrc/nms.hip tri_pair(): the n(n-1)/2 unordered pairs of n boxes as a rectangle of n rows and
+    n/2 columns, row r and column c pairing r with (r+1+c) mod n, the row recovered from the flat index
+    with one float multiply.  Restated here with the same float32 operations: every pair exactly once
+    for every n the kernels can meet (top_k <= 256)."""
+    import numpy as np
+    f32 = np.float32
+    for n in range(0, 258):
+        w = n >> 1
+        seen = set()
+        for x in range(n * w):
+            r = int(f32((f32(x) + f32(0.5)) * (f32(1.0) / f32(w))))
+            c = x - r * w
+            q = r + 1 + c
+            q = q - n if q >= n else q
+            if (n & 1) or c < w - 1 or r < w:
+                pr = (min(r, q), max(r, q))
+                assert pr[0] != pr[1] and pr not in seen, (n, x)
+                seen.add(pr)
+        assert len(seen) == n * (n - 1) // 2, n
