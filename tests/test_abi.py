@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     assert set(syms) == set(_lib.EXPORTS), (syms, _lib.EXPORTS)
     for s in syms:
         assert hasattr(L, s), s
-    assert L.yp_version() == 101
+    assert L.yp_version() == 200
 
 
 def test_config_struct_matches_header():
@@ -54,6 +54,9 @@ def _cfg(**kw):
     (dict(top_k=0), "top_k"), (dict(top_k=257), "top_k"), (dict(mask_dim=16), "mask_dim"),
     (dict(num_classes=1), "num_classes"), (dict(nms_mode=7), "nms_mode"), (dict(max_batch=0), "max_batch"),
     (dict(nms_mode=1, max_dets=300), "max_dets"),
+    (dict(proto_h=40000, proto_w=40000), "mask rows"),                  # 32-bit row offsets in mask_assemble
+    (dict(proto_h=2048, proto_w=2048, max_dets=300, top_k=15), "mask rows"),
+    (dict(num_anchors=1 << 24, max_batch=128), "max_batch*num_anchors"),
 ])
 def test_create_rejects_bad_config(kw, needle):
     L = _lib.load()

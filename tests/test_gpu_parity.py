@@ -370,3 +370,79 @@ def test_sharded_detect_matches_unsharded(torch_cuda):
               "detection_anchor_indices"):
         assert np.array_equal(one[k], two[k]), k
     assert two["num_detections"].shape == (5,)
+
+
+# ---- BASELINE.json configs 3, 4, 5 at the per-GPU batch sizes they state -------------------------
+_BATCH_CACHE = {}
+
+
+def _full_batch(cfg_id, nb):
+    """The first nb images of config cfg_id's batch (generated once per module run, sliced after)."""
+    from yolact_amd import synth
+    cfg = synth.CONFIGS[cfg_id]
+    if cfg_id not in _BATCH_CACHE:
+        _BATCH_CACHE.clear()                      # one config's batch of 64 at a time (2-3 GB of host memory)
+        _BATCH_CACHE[cfg_id] = synth.make_batch(cfg, batch=cfg.batch)
+    net, shp = _BATCH_CACHE[cfg_id]
+    return cfg, {k: (v if k == "priors" else v[:nb]) for k, v in net.items()}, shp
+
+
+@pytest.mark.parametrize("cfg_id,nb", [(3, 64), (3, 32), (3, 16), (3, 8), (5, 64), (5, 8), (4, 32)])
+def test_configs_at_their_stated_shard_sizes(torch_cuda, cfg_id, nb):
+    """Config 3 (768x1024, batch 64) whole and as the per-GPU shards of 2/4/8 GPUs (32/16/8 images),
+    config 5 (800x1333, batch 64) whole and as an 8-GPU shard, config 4 (NMS stress) at its batch of 32:
+    the batch size changes score_filter's work-item plan, mask_assemble's XCD placement and the
+    zero-fill's grid, so each size is checked bit for bit against the C restatement."""
+    cfg, net, shp = _full_batch(cfg_id, nb)
+    check_vs_c_oracle(torch_cuda, net, shp, mode="per_class", top_k=cfg.top_k, max_dets=cfg.max_dets, conf=cfg.conf_thresh,
+                      nthreads=16, label=f"cfg{cfg_id}-b{nb}")
+    if nb in (64, 32) and cfg_id != 3 or (cfg_id, nb) == (3, 64):
+        check_vs_c_oracle(torch_cuda, net, shp, mode="cc", top_k=cfg.top_k, max_dets=cfg.max_dets, conf=cfg.conf_thresh,
+                          nthreads=16, label=f"cfg{cfg_id}-b{nb}-cc")
+    _ = cfg
+
+
+@pytest.mark.parametrize("nb", [9, 12, 20])
+def test_batches_that_pad_the_xcd_placement(torch_cuda, nb):
+    """batch >= 8 and not a multiple of 8: mask_assemble's grid is padded to whole groups of 8 images and
+    the padding workgroups must return without touching anything."""
+    from yolact_amd import synth
+    net, shp = synth.make_toy(40 + nb, batch=nb, proto_hw=(23, 31))
+    check_vs_c_oracle(torch_cuda, net, shp, mode="per_class", top_k=50, max_dets=20, label=f"pad-{nb}")
+    check_vs_c_oracle(torch_cuda, net, shp, mode="cc", top_k=15, max_dets=15, label=f"pad-{nb}")
+
+
+def test_untouched_and_zero_rows_contract(torch_cuda):
+    """include/yolact_post.h, zero_pad_masks = 0: rows in [num_det, fill rows) are zeros, rows beyond the
+    rows a detection can land in keep what the caller had there."""
+    import torch
+    from yolact_amd import PostConfig, PostProcessor, synth
+    net, shp = synth.make_toy(5)
+    B, A, C = net["pred_cls"].shape
+    pp = PostProcessor(PostConfig(A, C, 12, 12, 64, 64, nms_mode="cc", top_k=15, max_dets=40, max_batch=B))
+    dev = {k: torch.from_numpy(v).cuda() for k, v in net.items()}
+    out = pp.alloc_outputs(B)
+    out["detection_masks"].fill_(7.0)
+    pp.run(dev["pred_offset"], dev["pred_cls"], dev["pred_mask_coef"], dev["priors"], dev["proto_out"], out=out)
+    pp.sync()
+    m, n = out["detection_masks"].cpu().numpy(), out["num_detections"].cpu().numpy()
+    for b in range(B):
+        assert n[b] <= 15 and not m[b, n[b]:15].any() and (m[b, 15:] == 7.0).all()
+    pp.close()
+
+
+def test_current_device_is_left_alone(torch_cuda):
+    """Every entry point restores the calling thread's HIP device (matters with one handle per GPU);
+    on the one-GPU box this checks that nothing else changes either."""
+    import torch
+    from yolact_amd import Detect, synth
+    from yolact_amd.sharding import ShardedDetect
+    net, shp = synth.make_toy(2)
+    before = torch.cuda.current_device()
+    det = Detect(5, 300, 100, 0.05, 0.5)
+    det(net, shp)
+    for pp in det._pp.values():
+        pp.close()
+    sd = ShardedDetect(5, 300, 100, 0.05, 0.5, devices=[0, 0])
+    sd(net, shp)
+    assert torch.cuda.current_device() == before

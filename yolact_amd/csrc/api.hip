@@ -31,10 +31,33 @@ static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 extern "C" const char* yp_last_error(void) { return g_err; }
 extern "C" int yp_version(void) { return YP_VERSION; }
 
-extern "C" int yp_create(const yp_config* cfg, yp_handle** out) {
-  if (!cfg || !out) return fail(YP_EINVAL, "yp_create: null argument");
-  *out = nullptr;
-  const yp_config& c = *cfg;
+// Every entry point leaves the calling thread's current HIP device as it found it.
+struct DeviceGuard {
+  int prev = -1;
+  hipError_t err = hipSuccess;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != dev) err = hipSetDevice(dev); else prev = -1;   // nothing to restore
+  }
+  ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+#define YP_ON_DEVICE(dev)                                                                          \
+  DeviceGuard guard_(dev);                                                                         \
+  if (guard_.err != hipSuccess) return fail(YP_EHIP, "hipSetDevice(%d) failed: %s", (dev), hipGetErrorString(guard_.err))
+
+static int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v && *v ? atoi(v) : dflt;
+}
+
+// Where the handle's buffers sit inside one scratch allocation of `total` bytes.
+struct ScratchLayout {
+  size_t cand, pool, crop, coef, cnt, n_cnt, max_items, total;
+};
+
+// Detect.__init__'s validation (detection.py:17-18) plus the limits of the kernels; fills the
+// host-side plan of `h` (no device memory is touched apart from attribute queries).
+static int plan_handle(const yp_config& c, yp_handle* h) {
   if (c.nms_thresh <= 0.0f) return fail(YP_EINVAL, "nms_threshold must be non negative.");   // detection.py:17-18
   if (c.num_anchors < 1 || c.num_anchors > (1 << 24)) return fail(YP_EINVAL, "num_anchors must be in [1, 2^24]");
   if (c.num_classes < 2 || c.num_classes > 256) return fail(YP_EINVAL, "num_classes (incl. background) must be in [2, 256]");
@@ -47,16 +70,25 @@ extern "C" int yp_create(const yp_config* cfg, yp_handle** out) {
     return fail(YP_EINVAL, "per-class mode: max_dets must be <= %d", YP_SORT_MAX);
   if (c.max_batch < 1) return fail(YP_EINVAL, "max_batch must be >= 1");
   if (!(c.conf_thresh >= 0.0f && c.conf_thresh < 1.0f)) return fail(YP_EINVAL, "conf_thresh must be in [0, 1)");
+  // mask_assemble addresses a detection's row as a 32-bit byte offset from the image's first row
+  const long long P = (long long)c.proto_h * c.proto_w;
+  const long long rows = c.max_dets < YP_SORT_MAX ? c.max_dets : YP_SORT_MAX;
+  if (P > (1ll << 28) || rows * P * 4 + 4096 >= (1ll << 32))
+    return fail(YP_EINVAL, "proto_h*proto_w = %lld with %lld detection rows exceeds the 4 GiB of mask rows per image the kernels address",
+                P, rows);
+  if ((long long)c.max_batch * c.num_anchors >= (1ll << 31))
+    return fail(YP_EINVAL, "max_batch*num_anchors must be below 2^31");
 
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(YP_ENODEV, "no HIP device available");
   if (c.device_id < 0 || c.device_id >= ndev) return fail(YP_ENODEV, "device_id %d out of range (%d devices)", c.device_id, ndev);
-  YP_HIP(hipSetDevice(c.device_id));
 
-  yp_handle* h = new (std::nothrow) yp_handle();
-  if (!h) return fail(YP_ENOMEM, "host allocation failed");
+  YP_ON_DEVICE(c.device_id);   // the occupancy / attribute queries below are about this device
   memset(h, 0, sizeof(*h));
   h->cfg = c;
+  h->tune.mask_nt = env_int("YP_TUNE_MASK_NT", 0);
+  h->tune.sf_waves = env_int("YP_TUNE_SF_WAVES", 0);
+  h->tune.fill_fork = env_int("YP_TUNE_FILL_FORK", 1);
   h->nseg = c.nms_mode == YP_NMS_CROSS_CLASS ? 1 : c.num_classes - 1;
   h->sel_rows = c.max_dets < YP_SORT_MAX ? c.max_dets : YP_SORT_MAX;
   h->lds_stride = (c.num_classes & 1) ? c.num_classes : c.num_classes + 1;   // odd stride: conflict-free rows
@@ -73,11 +105,10 @@ extern "C" int yp_create(const yp_config* cfg, yp_handle** out) {
   h->sf_bufb = (YP_SF_TA * h->lds_stride * (int)sizeof(float) + 15) / 16 * 16;
   h->ntiles = (c.num_anchors + YP_SF_TA - 1) / YP_SF_TA;
   h->sf_waves_per_cu = yp_score_filter_waves_per_cu(h);
-  const bool per_class = c.nms_mode == YP_NMS_PER_CLASS;
   {
     // Sum of probabilities <= 1 (+ rounding), so fewer than 1/conf classes of one anchor exceed conf.
     int kpa = 1;
-    if (per_class) {
+    if (c.nms_mode == YP_NMS_PER_CLASS) {
       kpa = c.num_classes - 1;
       if (c.conf_thresh > 0.0f) {
         const double lim = floor(1.0 / (double)c.conf_thresh) + 1.0;
@@ -86,9 +117,15 @@ extern "C" int yp_create(const yp_config* cfg, yp_handle** out) {
     }
     h->keys_per_anchor = kpa;
   }
-  const size_t B = (size_t)c.max_batch, nseg = (size_t)h->nseg;
+  return YP_OK;
+}
+
+// Scratch a planned handle needs to run batches of up to `max_batch` images.
+static ScratchLayout scratch_layout(const yp_handle* h, int max_batch) {
+  const bool per_class = h->cfg.nms_mode == YP_NMS_PER_CLASS;
+  const size_t B = (size_t)max_batch, nseg = (size_t)h->nseg;
   size_t cand_keys = 0, max_items = 0;   // the largest any batch size up to max_batch needs
-  for (int bs = 1; bs <= c.max_batch; ++bs) {
+  for (int bs = 1; bs <= max_batch; ++bs) {
     int parts; long long cap;
     yp_plan_items(h, bs, &parts, &cap);
     const size_t items = (size_t)bs * parts;
@@ -98,32 +135,62 @@ extern "C" int yp_create(const yp_config* cfg, yp_handle** out) {
   int ngroups, gcap;
   yp_plan_groups(h, &ngroups, &gcap);
   const size_t pool_per_img = per_class ? (size_t)ngroups * gcap : 0;
+  ScratchLayout L;
   size_t off = 0;
-  const size_t o_cand = off;  off = align_up(off + cand_keys * sizeof(u64), 256);
-  const size_t o_pool = off;  off = align_up(off + B * pool_per_img * sizeof(u64), 256);
-  const size_t o_crop = off;  off = align_up(off + B * h->sel_rows * sizeof(float4), 256);
-  const size_t o_coef = off;  off = align_up(off + B * h->sel_rows * YP_MASK_DIM * sizeof(float), 256);
-  const size_t o_cnt = off;   // all counters contiguous so one memset clears them
-  const size_t n_cnt = 2 * max_items + B * nseg + B;
-  off = align_up(off + n_cnt * sizeof(int32_t), 256);
-  h->scratch_bytes = (int64_t)off;
-  if (hipMalloc(&h->scratch_base, off) != hipSuccess) {
+  L.cand = off;  off = align_up(off + cand_keys * sizeof(u64), 256);
+  L.pool = off;  off = align_up(off + B * pool_per_img * sizeof(u64), 256);
+  L.crop = off;  off = align_up(off + B * h->sel_rows * sizeof(float4), 256);
+  L.coef = off;  off = align_up(off + B * h->sel_rows * YP_MASK_DIM * sizeof(float), 256);
+  L.cnt = off;   // all counters contiguous
+  L.max_items = max_items;
+  L.n_cnt = 2 * max_items + B * nseg + B;
+  off = align_up(off + L.n_cnt * sizeof(int32_t), 256);
+  L.total = off;
+  return L;
+}
+
+static void carve_scratch(yp_handle* h, const ScratchLayout& L, void* base_ptr, int max_batch) {
+  char* base = (char*)base_ptr;
+  h->s.cand = (u64*)(base + L.cand);
+  h->s.pool = (u64*)(base + L.pool);
+  h->s.crop = (float4*)(base + L.crop);
+  h->s.coef = (float*)(base + L.coef);
+  h->s.seg_count = (int32_t*)(base + L.cnt);
+  h->s.seg_surv = h->s.seg_count + L.max_items;
+  h->s.pool_count = h->s.seg_surv + L.max_items;
+  h->s.stat_surv = h->s.pool_count + (size_t)max_batch * h->nseg;
+}
+
+extern "C" int yp_create(const yp_config* cfg, yp_handle** out) {
+  if (!cfg || !out) return fail(YP_EINVAL, "yp_create: null argument");
+  *out = nullptr;
+  yp_handle* h = new (std::nothrow) yp_handle();
+  if (!h) return fail(YP_ENOMEM, "host allocation failed");
+  const int rc = plan_handle(*cfg, h);
+  if (rc != YP_OK) { delete h; return rc; }
+  DeviceGuard guard_(cfg->device_id);
+  if (guard_.err != hipSuccess) { delete h; return fail(YP_EHIP, "hipSetDevice(%d) failed", cfg->device_id); }
+  const ScratchLayout L = scratch_layout(h, cfg->max_batch);
+  h->scratch_bytes = (int64_t)L.total;
+  if (hipMalloc(&h->scratch_base, L.total) != hipSuccess) {
     delete h;
-    return fail(YP_ENOMEM, "hipMalloc of %zu scratch bytes failed", off);
+    return fail(YP_ENOMEM, "hipMalloc of %zu scratch bytes failed", L.total);
   }
-  char* base = (char*)h->scratch_base;
-  h->s.cand = (u64*)(base + o_cand);
-  h->s.pool = (u64*)(base + o_pool);
-  h->s.crop = (float4*)(base + o_crop);
-  h->s.coef = (float*)(base + o_coef);
-  h->s.seg_count = (int32_t*)(base + o_cnt);
-  h->s.seg_surv = h->s.seg_count + max_items;
-  h->s.pool_count = h->s.seg_surv + max_items;
-  h->s.stat_surv = h->s.pool_count + B * nseg;
-  if (hipMemset(h->s.seg_count, 0, n_cnt * sizeof(int32_t)) != hipSuccess) {
+  carve_scratch(h, L, h->scratch_base, cfg->max_batch);
+  int prio_least = 0, prio_greatest = 0;
+  (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+  bool ok = hipMemset(h->s.seg_count, 0, L.n_cnt * sizeof(int32_t)) == hipSuccess;
+  // the zero-fill's stream: lowest priority, so the NMS workgroups it runs beside are dispatched first
+  ok = ok && hipStreamCreateWithPriority(&h->aux_stream, hipStreamNonBlocking, prio_least) == hipSuccess;
+  ok = ok && hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) == hipSuccess;
+  ok = ok && hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) == hipSuccess;
+  if (!ok) {
+    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->aux_stream) (void)hipStreamDestroy(h->aux_stream);
     (void)hipFree(h->scratch_base);
     delete h;
-    return fail(YP_EHIP, "hipMemset of the counters failed");
+    return fail(YP_EHIP, "creating the handle's stream / events / counters failed");
   }
   (void)hipDeviceSynchronize();
 #ifdef YP_STAMPS
@@ -136,11 +203,60 @@ extern "C" int yp_create(const yp_config* cfg, yp_handle** out) {
 
 extern "C" int yp_destroy(yp_handle* h) {
   if (!h) return YP_OK;
-  (void)hipSetDevice(h->cfg.device_id);
+  DeviceGuard guard_(h->cfg.device_id);
   (void)hipDeviceSynchronize();
   if (h->profile) for (int i = 0; i <= YP_NUM_KERNELS; ++i) (void)hipEventDestroy(h->ev[i]);
+  (void)hipEventDestroy(h->ev_join);
+  (void)hipEventDestroy(h->ev_fork);
+  (void)hipStreamDestroy(h->aux_stream);
   (void)hipFree(h->scratch_base);
   delete h;
+  return YP_OK;
+}
+
+static int check_run_args(const yp_handle* h, const float* pred_offset, const float* pred_cls, const float* pred_mask_coef,
+                          const float* priors, const float* proto, float* det_boxes, float* det_classes, float* det_scores,
+                          float* det_masks, uint8_t* det_bitmaps, int32_t* num_det) {
+  if (!pred_offset || !pred_cls || !pred_mask_coef || !priors || !det_boxes || !det_classes || !det_scores || !num_det)
+    return fail(YP_EINVAL, "yp_run: null tensor pointer");
+  if (det_masks && !proto) return fail(YP_EINVAL, "yp_run: det_masks given without proto");
+  if (det_bitmaps && (!det_masks || h->cfg.mask_threshold < 0.0f))
+    return fail(YP_EINVAL, "yp_run: det_bitmaps needs det_masks and mask_threshold >= 0");
+  if ((((uintptr_t)pred_offset | (uintptr_t)priors | (uintptr_t)pred_mask_coef | (uintptr_t)det_boxes | (uintptr_t)proto) & 15u) != 0)
+    return fail(YP_EINVAL, "yp_run: pred_offset, priors, pred_mask_coef, proto and det_boxes must be 16-byte aligned");
+  return YP_OK;
+}
+
+// The launches of one batch.  The mask zero-fill depends on nothing the other kernels compute, so it
+// forks onto `aux` (event fork/join, no allocation) and runs beside the latency-bound NMS kernels,
+// which leave HBM idle; mask_assemble joins it.
+static int run_batch(yp_handle* h, int batch, const float* pred_offset, const float* pred_cls, const float* pred_mask_coef,
+                     const float* priors, const float* proto, float* det_boxes, float* det_classes, float* det_scores,
+                     float* det_masks, uint8_t* det_bitmaps, int32_t* num_det, int32_t* kept_anchor_idx, hipStream_t st,
+                     hipStream_t aux, hipEvent_t ev_fork, hipEvent_t ev_join) {
+  const bool prof = h->profile != 0;
+  auto fork_fill = [&]() -> int {
+    YP_HIP(hipEventRecord(ev_fork, st));
+    YP_HIP(hipStreamWaitEvent(aux, ev_fork, 0));
+    YP_HIP(yp_launch_mask_zero(h, batch, det_masks, det_bitmaps, aux));
+    YP_HIP(hipEventRecord(ev_join, aux));
+    return YP_OK;
+  };
+  if (prof) YP_HIP(hipEventRecord(h->ev[0], st));
+  if (det_masks && h->tune.fill_fork == 0) { const int rc = fork_fill(); if (rc) return rc; }
+  YP_HIP(yp_launch_score_filter(h, batch, pred_cls, st));
+  if (prof) YP_HIP(hipEventRecord(h->ev[1], st));
+  if (det_masks && h->tune.fill_fork != 0) { const int rc = fork_fill(); if (rc) return rc; }
+  YP_HIP(yp_launch_segment_nms(h, batch, pred_offset, priors, pred_mask_coef, det_boxes, det_classes, det_scores, num_det, kept_anchor_idx, st));
+  if (prof) YP_HIP(hipEventRecord(h->ev[2], st));
+  if (h->cfg.nms_mode == YP_NMS_PER_CLASS)
+    YP_HIP(yp_launch_final_select(h, batch, pred_offset, priors, pred_mask_coef, det_boxes, det_classes, det_scores, num_det, kept_anchor_idx, st));
+  if (prof) YP_HIP(hipEventRecord(h->ev[3], st));
+  if (det_masks) {
+    YP_HIP(hipStreamWaitEvent(st, ev_join, 0));
+    YP_HIP(yp_launch_mask_assemble(h, batch, proto, num_det, det_masks, det_bitmaps, st));
+  }
+  if (prof) YP_HIP(hipEventRecord(h->ev[4], st));
   return YP_OK;
 }
 
@@ -150,35 +266,21 @@ extern "C" int yp_run(yp_handle* h, int32_t batch, const float* pred_offset, con
                       int32_t* num_det, int32_t* kept_anchor_idx, void* hip_stream) {
   if (!h) return fail(YP_EINVAL, "yp_run: null handle");
   if (batch < 0 || batch > h->cfg.max_batch) return fail(YP_EINVAL, "batch %d outside [0, max_batch=%d]", batch, h->cfg.max_batch);
-  if (!pred_offset || !pred_cls || !pred_mask_coef || !priors || !det_boxes || !det_classes || !det_scores || !num_det)
-    return fail(YP_EINVAL, "yp_run: null tensor pointer");
-  if (det_masks && !proto) return fail(YP_EINVAL, "yp_run: det_masks given without proto");
-  if (det_bitmaps && (!det_masks || h->cfg.mask_threshold < 0.0f))
-    return fail(YP_EINVAL, "yp_run: det_bitmaps needs det_masks and mask_threshold >= 0");
-  if ((((uintptr_t)pred_offset | (uintptr_t)priors | (uintptr_t)pred_mask_coef | (uintptr_t)det_boxes | (uintptr_t)proto) & 15u) != 0)
-    return fail(YP_EINVAL, "yp_run: pred_offset, priors, pred_mask_coef, proto and det_boxes must be 16-byte aligned");
+  const int rc = check_run_args(h, pred_offset, pred_cls, pred_mask_coef, priors, proto, det_boxes, det_classes, det_scores,
+                                det_masks, det_bitmaps, num_det);
+  if (rc != YP_OK) return rc;
   if (batch == 0) return YP_OK;
   hipStream_t st = (hipStream_t)hip_stream;
-  YP_HIP(hipSetDevice(h->cfg.device_id));
+  YP_ON_DEVICE(h->cfg.device_id);
   h->last_stream = st;
   h->last_batch = batch;
-  const bool prof = h->profile != 0;
-  if (prof) YP_HIP(hipEventRecord(h->ev[0], st));
-  YP_HIP(yp_launch_score_filter(h, batch, pred_cls, st));
-  if (prof) YP_HIP(hipEventRecord(h->ev[1], st));
-  YP_HIP(yp_launch_segment_nms(h, batch, pred_offset, priors, pred_mask_coef, det_boxes, det_classes, det_scores, num_det, kept_anchor_idx, st));
-  if (prof) YP_HIP(hipEventRecord(h->ev[2], st));
-  if (h->cfg.nms_mode == YP_NMS_PER_CLASS)
-    YP_HIP(yp_launch_final_select(h, batch, pred_offset, priors, pred_mask_coef, det_boxes, det_classes, det_scores, num_det, kept_anchor_idx, st));
-  if (prof) YP_HIP(hipEventRecord(h->ev[3], st));
-  if (det_masks) YP_HIP(yp_launch_mask_assemble(h, batch, proto, num_det, det_masks, det_bitmaps, st));
-  if (prof) YP_HIP(hipEventRecord(h->ev[4], st));
-  return YP_OK;
+  return run_batch(h, batch, pred_offset, pred_cls, pred_mask_coef, priors, proto, det_boxes, det_classes, det_scores,
+                   det_masks, det_bitmaps, num_det, kept_anchor_idx, st, h->aux_stream, h->ev_fork, h->ev_join);
 }
 
 extern "C" int yp_sync(yp_handle* h) {
   if (!h) return fail(YP_EINVAL, "yp_sync: null handle");
-  YP_HIP(hipSetDevice(h->cfg.device_id));
+  YP_ON_DEVICE(h->cfg.device_id);
   YP_HIP(hipStreamSynchronize(h->last_stream));
   return YP_OK;
 }
@@ -186,7 +288,7 @@ extern "C" int yp_sync(yp_handle* h) {
 extern "C" int yp_last_survivors(yp_handle* h, int32_t* host_out, int32_t batch) {
   if (!h || !host_out) return fail(YP_EINVAL, "yp_last_survivors: null argument");
   if (batch < 0 || batch > h->cfg.max_batch) return fail(YP_EINVAL, "bad batch");
-  YP_HIP(hipSetDevice(h->cfg.device_id));
+  YP_ON_DEVICE(h->cfg.device_id);
   YP_HIP(hipStreamSynchronize(h->last_stream));
   YP_HIP(hipMemcpy(host_out, h->s.stat_surv, sizeof(int32_t) * (size_t)batch, hipMemcpyDeviceToHost));
   return YP_OK;
@@ -194,7 +296,7 @@ extern "C" int yp_last_survivors(yp_handle* h, int32_t* host_out, int32_t batch)
 
 extern "C" int yp_profile_enable(yp_handle* h, int32_t on) {
   if (!h) return fail(YP_EINVAL, "yp_profile_enable: null handle");
-  YP_HIP(hipSetDevice(h->cfg.device_id));
+  YP_ON_DEVICE(h->cfg.device_id);
   if (on && !h->profile) {
     for (int i = 0; i <= YP_NUM_KERNELS; ++i) YP_HIP(hipEventCreate(&h->ev[i]));
     h->profile = 1;
@@ -209,7 +311,7 @@ extern "C" int yp_profile_enable(yp_handle* h, int32_t on) {
 extern "C" int yp_profile_read(yp_handle* h, float* ms_out) {
   if (!h || !ms_out) return fail(YP_EINVAL, "yp_profile_read: null argument");
   if (!h->profile) return fail(YP_EINVAL, "profiling is not enabled");
-  YP_HIP(hipSetDevice(h->cfg.device_id));
+  YP_ON_DEVICE(h->cfg.device_id);
   YP_HIP(hipEventSynchronize(h->ev[YP_NUM_KERNELS]));
   for (int i = 0; i < YP_NUM_KERNELS; ++i) YP_HIP(hipEventElapsedTime(&ms_out[i], h->ev[i], h->ev[i + 1]));
   return YP_OK;
@@ -242,7 +344,7 @@ extern "C" int64_t yp_make_priors(int32_t img_h, int32_t img_w, int32_t num_leve
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(YP_ENODEV, "no HIP device available");
   if (device_id < 0 || device_id >= ndev) return fail(YP_ENODEV, "device_id %d out of range (%d devices)", device_id, ndev);
-  YP_HIP(hipSetDevice(device_id));
+  YP_ON_DEVICE(device_id);
   YP_HIP(yp_launch_make_priors(img_h, img_w, num_levels, fmap_hw, scales, num_ratios, sq, priors, (hipStream_t)hip_stream));
   return n;
 }

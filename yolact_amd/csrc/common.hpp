@@ -111,8 +111,20 @@ struct yp_scratch {
   float* coef;          // [max_batch][sel_rows][32] coefficients of the kept detections
 };
 
+// Experiment knobs, read from the environment ONCE, in yp_create (never on the launch path):
+//   YP_TUNE_MASK_NT=1        mask_assemble stores its rows non-temporally
+//   YP_TUNE_SF_WAVES=<n>     score_filter: single-wave workgroups per CU the plan assumes
+//   YP_TUNE_FILL_FORK=0|1    where the mask zero-fill forks off the caller's stream: 0 = at the start of
+//                            yp_run (beside score_filter), 1 = after score_filter (beside the NMS; default)
+struct yp_tune {
+  int mask_nt;
+  int sf_waves;
+  int fill_fork;
+};
+
 struct yp_handle {
   yp_config cfg;
+  yp_tune tune;
   int nseg;             // segments per image: 1 (cross-class) or C-1 (per-class)
   int sel_rows;         // min(max_dets, YP_SORT_MAX): rows a detection can land in
   int lds_stride;       // floats per anchor row in score_filter's LDS tile
@@ -128,6 +140,8 @@ struct yp_handle {
   void* scratch_base;
   int64_t scratch_bytes;
   yp_scratch s;
+  hipStream_t aux_stream;   // the mask zero-fill runs here, beside the NMS kernels on the caller's stream
+  hipEvent_t ev_fork, ev_join;
   hipStream_t last_stream;
   int last_batch;
   int profile;
@@ -172,5 +186,7 @@ hipError_t yp_launch_final_select(const yp_handle* h, int batch, const float* pr
                                   const float* pred_mask_coef, float* det_boxes,
                                   float* det_classes, float* det_scores, int32_t* num_det, int32_t* kept_idx,
                                   hipStream_t st);
+int yp_mask_fill_rows(const yp_handle* h);
+hipError_t yp_launch_mask_zero(const yp_handle* h, int batch, float* det_masks, uint8_t* det_bitmaps, hipStream_t st);
 hipError_t yp_launch_mask_assemble(const yp_handle* h, int batch, const float* proto, const int32_t* num_det,
                                    float* det_masks, uint8_t* det_bitmaps, hipStream_t st);

@@ -10,7 +10,7 @@
 // HBM exactly once; the coefficients and crop edges of a detection are wave-uniform and come in
 // through scalar loads.  The dot product is a K-ordered fma chain (YP-MATH) and is only evaluated
 // by waves whose 64 pixels can lie inside the detection's crop box; everything else is zeros, written
-// in bulk (pass Z below, or mask_zero_kernel for outputs beyond the Infinity Cache).
+// in bulk by mask_zero_kernel, which does not depend on the NMS and runs beside it (yp_run).
 // Output is written [N][P] (pixel-contiguous), which is the reference's final layout.
 #include <stdlib.h>
 #include "common.hpp"
@@ -22,8 +22,7 @@ struct MaskArgs {
   const int32_t* num_det;  // [B]
   float* masks;            // [B,max_dets,P]
   uint8_t* bitmaps;        // [B,max_dets,P] or null
-  int P, pw, max_dets, sel_rows, zero_pad;
-  int prezeroed;           // 1: mask_zero_kernel has already zero-filled every row this kernel would
+  int P, pw, max_dets, sel_rows;
   float mask_threshold;
 };
 
@@ -35,20 +34,20 @@ struct MaskArgs {
 //      coalesced NON-TEMPORAL 16-byte loads (read once, by nobody else: they must not displace the
 //      output lines that live in L2 / Infinity Cache) and transposed through LDS, so that every lane
 //      ends up with its pixel's 32 values in VGPRs;
-//   2. pass Z: every row of the workgroup's pixels gets zeros (16-byte stores, 1 KiB per
-//      wave-instruction); pass R: the detections whose crop box can touch the wave's pixels (one bit
-//      each, found with ctz) get the K-ordered fma chain + sigmoid + crop and are stored again.
+//   2. the rows were zero-filled beforehand (mask_zero_kernel); the detections whose crop box can touch
+//      the wave's pixels (one bit each, found with ctz) get the K-ordered fma chain + sigmoid + crop
+//      and are stored over the zeros.
 // Workgroups of one image are placed on one XCD (the dispatcher deals consecutive workgroup ids
 // round-robin over the 8 XCDs), so the partial cache lines at workgroup borders (mask rows are
 // only 16-byte aligned: P*4 bytes is not a multiple of 128) merge in a single L2.
 template <bool NT_STORE>
-__global__ __launch_bounds__(YP_MASK_BLOCK) void mask_assemble_kernel(const MaskArgs p, int blocks_per_image, int batch) {
+__global__ __launch_bounds__(YP_MASK_BLOCK) void mask_assemble_kernel(const MaskArgs p, int blocks_per_image, int batch, int by_xcd) {
   __shared__ float4 sproto[YP_MASK_BLOCK * YP_MASK_ROW4];
   typedef float nat4 __attribute__((ext_vector_type(4)));
   const int t = threadIdx.x;
-  // batch >= 8: image b on XCD b % 8 (see above).  Smaller batches would leave XCDs idle that way and
-  // take the plain order instead (gridDim.x == batch * blocks_per_image then).
-  const bool by_xcd = gridDim.x != (unsigned)(batch * blocks_per_image);
+  // by_xcd (batch >= 8, grid padded to a multiple of 8 images): image b on the XCD that takes the
+  // workgroup ids congruent to b % 8.  Smaller batches would leave XCDs idle that way and take the
+  // plain order instead.
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
   const int b = by_xcd ? (slot / blocks_per_image) * 8 + xcd : (int)blockIdx.x / blocks_per_image;
   if (b >= batch) return;
@@ -57,20 +56,50 @@ __global__ __launch_bounds__(YP_MASK_BLOCK) void mask_assemble_kernel(const Mask
   const int pix = base_pix + t;
   const bool live = t < npx;
   const int N = __builtin_amdgcn_readfirstlane(min(p.num_det[b], p.sel_rows));   // wave-uniform
+  // The block's 256 x 32 prototype values (32 KiB, contiguous in HBM): fully coalesced NON-TEMPORAL
+  // 16-byte loads (read once, by nobody else), issued first so that they are in flight while the
+  // detection rows are looked at.  Thread t's float4 number i is quad (t & 7) of pixel i*32 + (t >> 3).
+  const nat4* src = reinterpret_cast<const nat4*>(p.proto + ((size_t)b * p.P + base_pix) * YP_MASK_DIM);
+  nat4 x[YP_MASK_DIM / 4];
+#pragma unroll
+  for (int i = 0; i < YP_MASK_DIM / 4; ++i) {
+    const int idx = i * YP_MASK_BLOCK + t;
+    x[i] = __builtin_nontemporal_load(src + min(idx, npx * (YP_MASK_DIM / 4) - 1));
+  }
+
+  // Which detections can touch this wave's 64 pixels at all?  Lane l tests detection g*64+l against
+  // a bounding range of the wave's pixels (a superset test: the per-pixel compares below decide the
+  // values); the ballots give a bit per detection.  Rows of all other detections keep the zeros that
+  // mask_zero_kernel wrote.  Everything wave-uniform is kept in SGPRs on purpose (readfirstlane where
+  // the compiler cannot prove it), so that walking the bits is scalar work.
+  const int lane = t & 63;
+  const int w0 = base_pix + __builtin_amdgcn_readfirstlane(t >> 6) * 64, w1 = min(w0 + 63, p.P - 1);
+  u64 rel[YP_SORT_MAX / 64] = {0ull, 0ull, 0ull, 0ull};
+  if (w0 < p.P) {
+    const int r0 = w0 / p.pw, r1 = w1 / p.pw;
+    int c0 = w0 - r0 * p.pw, c1 = w1 - r1 * p.pw;
+    if (r1 > r0) { c0 = 0; c1 = p.pw - 1; }
+    const float fr0 = (float)r0, fr1 = (float)r1, fc0 = (float)c0, fc1 = (float)c1;
+#pragma unroll
+    for (int g = 0; g < YP_SORT_MAX / 64; ++g) {
+      if (g * 64 < N) {
+        const int n = g * 64 + lane;
+        const float4 cb = p.crop[(size_t)b * p.sel_rows + min(n, N - 1)];
+        const bool hit = (n < N) && (fc1 >= cb.x) && (fc0 < cb.y) && (fr1 >= cb.z) && (fr0 < cb.w);
+        const u64 m = __ballot(hit);
+        rel[g] = ((u64)(uint32_t)__builtin_amdgcn_readfirstlane((int)(m >> 32)) << 32) |
+                 (u64)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)m);
+      }
+    }
+  }
+  // A workgroup none of whose waves is touched by any detection has nothing to read or write.
+  if (__syncthreads_or((rel[0] | rel[1] | rel[2] | rel[3]) != 0ull) == 0) return;
 
   float pr[YP_MASK_DIM];
   {
-    // Thread t's float4 number i of the block's 32 KiB is quad (t & 7) of pixel i*32 + (t >> 3).  The
-    // transpose goes through LDS two quads at a time (four passes over a 12 KiB buffer instead of one
+    // The transpose goes through LDS two quads at a time (four passes over a 12 KiB buffer instead of one
     // pass over 36 KiB): LDS is what limits residency here, and with it the waves that hide each
     // other's latencies.
-    const nat4* src = reinterpret_cast<const nat4*>(p.proto + ((size_t)b * p.P + base_pix) * YP_MASK_DIM);
-    nat4 x[YP_MASK_DIM / 4];
-#pragma unroll
-    for (int i = 0; i < YP_MASK_DIM / 4; ++i) {
-      const int idx = i * YP_MASK_BLOCK + t;
-      x[i] = __builtin_nontemporal_load(src + min(idx, npx * (YP_MASK_DIM / 4) - 1));
-    }
 #pragma unroll
     for (int q = 0; q < YP_MASK_DIM / 8; ++q) {
       if (q > 0) __syncthreads();            // the previous pass has been read
@@ -96,71 +125,12 @@ __global__ __launch_bounds__(YP_MASK_BLOCK) void mask_assemble_kernel(const Mask
   cfloat* const crop_c = (cfloat*)(p.crop + (size_t)b * p.sel_rows);
   cfloat* const coef_c = (cfloat*)(p.coef + (size_t)b * p.sel_rows * YP_MASK_DIM);
 
-  // Which detections can touch this wave's 64 pixels at all?  Lane l tests detection g*64+l against
-  // a bounding range of the wave's pixels (a superset test: the per-pixel compares below decide the
-  // values); the ballots give a bit per detection.  Rows of all other detections are plain zeros.
-  // Everything wave-uniform is kept in SGPRs on purpose (readfirstlane where the compiler cannot
-  // prove it), so that walking the bits is scalar work.
-  const int lane = t & 63;
-  const int w0 = base_pix + __builtin_amdgcn_readfirstlane(t >> 6) * 64, w1 = min(w0 + 63, p.P - 1);
-  u64 rel[YP_SORT_MAX / 64] = {0ull, 0ull, 0ull, 0ull};
-  if (w0 < p.P) {
-    const int r0 = w0 / p.pw, r1 = w1 / p.pw;
-    int c0 = w0 - r0 * p.pw, c1 = w1 - r1 * p.pw;
-    if (r1 > r0) { c0 = 0; c1 = p.pw - 1; }
-    const float fr0 = (float)r0, fr1 = (float)r1, fc0 = (float)c0, fc1 = (float)c1;
-#pragma unroll
-    for (int g = 0; g < YP_SORT_MAX / 64; ++g) {
-      if (g * 64 < N) {
-        const int n = g * 64 + lane;
-        const float4 cb = p.crop[(size_t)b * p.sel_rows + min(n, N - 1)];
-        const bool hit = (n < N) && (fc1 >= cb.x) && (fc0 < cb.y) && (fr1 >= cb.z) && (fr0 < cb.w);
-        const u64 m = __ballot(hit);
-        rel[g] = ((u64)(uint32_t)__builtin_amdgcn_readfirstlane((int)(m >> 32)) << 32) |
-                 (u64)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)m);
-      }
-    }
-  }
   // The CU's scalar unit is shared by all its waves, and a loop over every detection with a test and
-  // a branch per row is bound by it (measured: ~36 of 62 us with no memory traffic at all).  So:
-  //   pass Z  every row gets zeros: one store + one vector add per row, nothing scalar but the loop
-  //   pass R  only the rows whose bit is set (found with ctz) are computed and stored again, after
-  //           the zeros have been acknowledged (vmcnt(0), plus a barrier where another wave wrote them)
+  // a branch per row is bound by it (measured: ~36 of 62 us with no memory traffic at all).  So only
+  // the rows whose bit is set (found with ctz) are visited at all.
   const uint32_t voff = (uint32_t)t * 4u;
-  const uint32_t rstride = (uint32_t)p.P * 4u;
+  const uint32_t rstride = (uint32_t)p.P * 4u;     // yp_create bounds sel_rows * P * 4 below 2^32
   const bool plain = !NT_STORE && brow == nullptr;
-  const bool wide = plain && (p.P & 3) == 0 && ((uintptr_t)p.masks & 15u) == 0;
-  if (p.prezeroed) {
-    // nothing: the rows are zero already and only the detections that touch this wave are rewritten
-  } else if (wide) {
-    // the workgroup's 256 pixels of a row are 1 KiB: one 16-byte store per lane zeroes a whole row
-    // segment (eight full lines), wave w taking rows w, w+4, ...  The rows are then rewritten by the
-    // waves that own their pixels, so these stores must have completed first.
-    const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
-    if (lane < (npx >> 2)) {
-      uint32_t vo = (uint32_t)lane * 16u + (uint32_t)wv * rstride;
-      const nat4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
-      const int nz = p.zero_pad ? p.max_dets : N;   // tf.zeros rows of detection.py:68 included
-      for (int n = wv; n < nz; n += YP_MASK_BLOCK / 64, vo += (YP_MASK_BLOCK / 64) * rstride)
-        asm volatile("global_store_dwordx4 %0, %1, %2" ::"v"(vo), "v"(zero4), "s"(orow) : "memory");
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-  } else if (live) {
-    if (plain) {
-      uint32_t vo = voff;
-      const float zero = 0.0f;
-      for (int n = 0; n < N; ++n, vo += rstride)
-        asm volatile("global_store_dword %0, %1, %2" ::"v"(vo), "v"(zero), "s"(orow) : "memory");
-    } else {
-      for (int n = 0; n < N; ++n) {
-        if (NT_STORE) __builtin_nontemporal_store(0.0f, orow + (size_t)n * p.P + t); else orow[(size_t)n * p.P + t] = 0.0f;
-        if (brow) brow[(size_t)n * p.P + t] = 0.0f > p.mask_threshold ? 1 : 0;               // train.py:497
-      }
-    }
-  }
-  // per-wave zero pass: this wave rewrites its own addresses below; its zeros are acknowledged first
-  if (!p.prezeroed && !wide) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
   for (int g = 0; g < YP_SORT_MAX / 64; ++g) {
     u64 w = g * 64 < N ? rel[g] : 0ull;        // wave-uniform
@@ -192,27 +162,17 @@ __global__ __launch_bounds__(YP_MASK_BLOCK) void mask_assemble_kernel(const Mask
       }
     }
   }
-  float* const out_img = p.masks + (size_t)b * p.max_dets * p.P;
-  uint8_t* const bit_img = p.bitmaps ? p.bitmaps + (size_t)b * p.max_dets * p.P : nullptr;
-  if (p.zero_pad && live && !wide && !p.prezeroed) {   // tf.zeros rows of detection.py:68 (the wide zero pass has written them already)
-    for (int n = N; n < p.max_dets; ++n) {
-      const size_t o = (size_t)n * p.P + pix;
-      out_img[o] = 0.0f;
-      if (bit_img) bit_img[o] = 0;
-    }
-  }
 }
 
 // Zero-fill of the mask rows as one linear stream per image (rows 0 .. nz-1 of an image are
-// contiguous): the form in which HBM takes writes fastest (a plain fill reaches 6.8 TB/s on 0.7-1.3 GB,
-// the 1 KiB pieces of the fused zero pass ~4 TB/s once the output no longer fits the Infinity Cache).
-// ESIZE = bytes per element (4: float masks, 1: bitmaps).  Workgroup (c, b) fills bytes
-// [c*16 KiB, (c+1)*16 KiB) of image b's region.
+// contiguous): the form in which HBM takes writes fastest (a plain fill reaches 6.8 TB/s on 0.7-1.3 GB).
+// It depends on nothing the NMS computes - nz is a host-side bound on the rows detections can land
+// in - so yp_run issues it on the handle's second stream, beside the latency-bound NMS kernels that
+// leave HBM idle.  ESIZE = bytes per element (4: float masks, 1: bitmaps).  Workgroup (c, b) fills
+// bytes [c*16 KiB, (c+1)*16 KiB) of image b's region.
 template <int ESIZE>
-__global__ __launch_bounds__(256) void mask_zero_kernel(void* out, const int32_t* num_det, long long P, int max_dets, int sel_rows,
-                                                        int zero_pad) {
+__global__ __launch_bounds__(256) void mask_zero_kernel(void* out, long long P, int max_dets, int nz) {
   const int b = blockIdx.y;
-  const int nz = zero_pad ? max_dets : min(num_det[b], sel_rows);
   const long long len = (long long)nz * P * ESIZE;                 // bytes to clear
   char* const base = reinterpret_cast<char*>(out) + (long long)b * max_dets * P * ESIZE;
   const long long lo = (long long)blockIdx.x * 16384;
@@ -233,41 +193,42 @@ __global__ __launch_bounds__(256) void mask_zero_kernel(void* out, const int32_t
   }
 }
 
+// Rows [0, yp_mask_fill_rows) of every image are zero-filled before mask_assemble runs: every row a
+// detection can land in (and, with zero_pad_masks, the tf.zeros rows of detection.py:68 as well).
+int yp_mask_fill_rows(const yp_handle* h) {
+  const yp_config& c = h->cfg;
+  if (c.zero_pad_masks) return c.max_dets;
+  int rows = h->sel_rows;                                                   // min(max_dets, 256)
+  if (c.nms_mode == YP_NMS_CROSS_CLASS && c.top_k < rows) rows = c.top_k;   // N <= k (detection.py:186)
+  return rows;
+}
+
+hipError_t yp_launch_mask_zero(const yp_handle* h, int batch, float* det_masks, uint8_t* det_bitmaps, hipStream_t st) {
+  const long long P = (long long)h->cfg.proto_h * h->cfg.proto_w;
+  const int nz = yp_mask_fill_rows(h);
+  const long long region = (long long)nz * P;
+  hipLaunchKernelGGL((mask_zero_kernel<4>), dim3((unsigned)((region * 4 + 16383) / 16384), batch), dim3(256), 0, st,
+                     (void*)det_masks, P, h->cfg.max_dets, nz);
+  if (det_bitmaps)
+    hipLaunchKernelGGL((mask_zero_kernel<1>), dim3((unsigned)((region + 16383) / 16384), batch), dim3(256), 0, st,
+                       (void*)det_bitmaps, P, h->cfg.max_dets, nz);
+  return hipGetLastError();
+}
+
 hipError_t yp_launch_mask_assemble(const yp_handle* h, int batch, const float* proto, const int32_t* num_det,
                                    float* det_masks, uint8_t* det_bitmaps, hipStream_t st) {
   MaskArgs a;
   a.proto = proto; a.coef = h->s.coef; a.crop = h->s.crop; a.num_det = num_det;
   a.masks = det_masks; a.bitmaps = det_bitmaps;
   a.P = h->cfg.proto_h * h->cfg.proto_w; a.pw = h->cfg.proto_w;
-  a.max_dets = h->cfg.max_dets; a.sel_rows = h->sel_rows; a.zero_pad = h->cfg.zero_pad_masks;
+  a.max_dets = h->cfg.max_dets; a.sel_rows = h->sel_rows;
   a.mask_threshold = h->cfg.mask_threshold;
-  // Default-policy stores: the masks of the previous call usually still sit (dirty) in the
-  // Infinity Cache, and a caller that reuses its output buffer overwrites them there.
-  const bool nt = getenv("YP_MASK_NT") ? atoi(getenv("YP_MASK_NT")) != 0 : false;
   const int bpi = (a.P + YP_MASK_BLOCK - 1) / YP_MASK_BLOCK;
-  const dim3 grid(batch >= 8 ? 8 * ((batch + 7) / 8) * bpi : batch * bpi);
-  // Residency by LDS padding.  Masks that fit the 256 MiB Infinity Cache are absorbed there and the
-  // kernel wants as many waves as it can get (8 workgroups per CU).  Larger outputs stream to HBM,
-  // where fewer concurrent write streams keep more DRAM pages open: 2 workgroups per CU measured
-  // best (config 5: 499 -> 442 us).
-  const size_t out_bytes = (size_t)batch * a.max_dets * a.P * sizeof(float);
-  const bool big = out_bytes > ((size_t)256 << 20);
-  // Outputs beyond the Infinity Cache: the zeros go out first, as a linear fill; mask_assemble then
-  // only writes the rows that detections touch.  (Inside the cache the fused zero pass is as fast
-  // and saves a launch.)
-  a.prezeroed = big ? 1 : 0;
-  if (const char* ev = getenv("YP_MASK_PREZERO")) a.prezeroed = atoi(ev) != 0;   // tuning knob
-  if (a.prezeroed) {
-    const long long region = (long long)a.max_dets * a.P;
-    hipLaunchKernelGGL((mask_zero_kernel<4>), dim3((unsigned)((region * 4 + 16383) / 16384), batch), dim3(256), 0, st,
-                       (void*)det_masks, num_det, (long long)a.P, a.max_dets, a.sel_rows, a.zero_pad);
-    if (det_bitmaps)
-      hipLaunchKernelGGL((mask_zero_kernel<1>), dim3((unsigned)((region + 16383) / 16384), batch), dim3(256), 0, st,
-                         (void*)det_bitmaps, num_det, (long long)a.P, a.max_dets, a.sel_rows, a.zero_pad);
-  }
-  size_t pad = (big && !a.prezeroed) ? 66000 : 0;
-  if (const char* ev = getenv("YP_MASK_LDS_PAD")) pad = (size_t)atoi(ev);   // tuning knob
-  if (nt) hipLaunchKernelGGL((mask_assemble_kernel<true>), grid, dim3(YP_MASK_BLOCK), pad, st, a, bpi, batch);
-  else hipLaunchKernelGGL((mask_assemble_kernel<false>), grid, dim3(YP_MASK_BLOCK), pad, st, a, bpi, batch);
+  const int by_xcd = batch >= 8 ? 1 : 0;
+  const dim3 grid(by_xcd ? 8 * ((batch + 7) / 8) * bpi : batch * bpi);
+  // Default-policy stores: the zeros the fill has just written usually still sit (dirty) in the
+  // Infinity Cache, and these stores overwrite them there.  (tune.mask_nt: non-temporal instead.)
+  if (h->tune.mask_nt) hipLaunchKernelGGL((mask_assemble_kernel<true>), grid, dim3(YP_MASK_BLOCK), 0, st, a, bpi, batch, by_xcd);
+  else hipLaunchKernelGGL((mask_assemble_kernel<false>), grid, dim3(YP_MASK_BLOCK), 0, st, a, bpi, batch, by_xcd);
   return hipGetLastError();
 }

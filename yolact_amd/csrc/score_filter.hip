@@ -362,7 +362,7 @@ int yp_score_filter_waves_per_cu(const yp_handle* h) {
   int per_cu = (int)(128 / ((lds + 1279) / 1280));
   int api = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&api, kernel_of(h), YP_WAVE, lds) == hipSuccess && api > 0 && api < per_cu) per_cu = api;
-  if (const char* ev = getenv("YP_SF_WAVES_PER_CU")) { const int v = atoi(ev); if (v > 0) per_cu = v; }   // tuning knob
+  if (h->tune.sf_waves > 0) per_cu = h->tune.sf_waves;   // experiment knob (yp_tune)
   return per_cu < 1 ? 1 : (per_cu > 32 ? 32 : per_cu);
 }
 

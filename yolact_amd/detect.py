@@ -229,6 +229,7 @@ class Detect(object):
         if pp is None or pp.cfg.max_batch < B:
             if pp is not None:
                 pp.close()
+            # (the library restores the caller's current device in every entry point, destroy included)
             pp = PostProcessor(PostConfig(
                 num_anchors=A, num_classes=C, proto_h=proto_h, proto_w=proto_w, img_h=H, img_w=W,
                 conf_thresh=float(self.conf_thresh), nms_thresh=float(self.iou_thresh), nms_mode=self.nms_mode,

@@ -61,26 +61,34 @@ def gather_results(local: dict | None, dst: int = 0):
 
 
 class ShardedDetect:
-    """`Detect` over several GPUs of one node from a single process."""
+    """`Detect` over several GPUs of one node from a single process.
+
+    One worker thread per device: a shard's host-to-device copies, its launches and its copy back all
+    happen on that device's thread (torch releases the GIL inside the copies, HIP's current device is
+    per thread), so the devices really run side by side; the caller's thread only concatenates."""
 
     def __init__(self, *detect_args, devices=None, **detect_kwargs):
         import torch
+        from concurrent.futures import ThreadPoolExecutor
         from .detect import Detect
         if not torch.cuda.is_available():
             raise RuntimeError("ShardedDetect needs HIP devices; there is no CPU fallback")
         self.devices = list(devices) if devices is not None else list(range(torch.cuda.device_count()))
         self.detects = [Detect(*detect_args, device=f"cuda:{d}", **detect_kwargs) for d in self.devices]
+        self._pool = ThreadPoolExecutor(max_workers=max(1, len(self.devices)), thread_name_prefix="yp-shard")
 
     def __call__(self, net_outs, img_shape, trad_nms=False, use_cropped_mask=True):
         import torch
         B = int(net_outs["pred_cls"].shape[0])
         G = len(self.devices)
-        parts = []
-        for r, det in enumerate(self.detects):            # launches are asynchronous: devices overlap
+
+        def work(r):
             lo, hi = shard_bounds(B, G, r)
-            if hi > lo:
-                parts.append(det(slice_net_outs(net_outs, lo, hi), img_shape, trad_nms, use_cropped_mask))
-        host = []
-        for p in parts:                                   # gather on the host, in image order
-            host.append({k: v.cpu() for k, v in p.items()})
-        return concat_results(host)
+            if hi <= lo:
+                return None
+            with torch.cuda.device(self.detects[r].device):
+                res = self.detects[r](slice_net_outs(net_outs, lo, hi), img_shape, trad_nms, use_cropped_mask)
+                return {k: v.cpu() for k, v in res.items()}
+
+        futures = [self._pool.submit(work, r) for r in range(G)]      # every shard is in flight before any is awaited
+        return concat_results([f.result() for f in futures])             # image order
