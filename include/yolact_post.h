@@ -18,14 +18,16 @@
  * Every entry point leaves the calling thread's current HIP device unchanged.
  * There is no CPU backend: without a HIP device yp_create fails.
  *
- * Inside yp_run the zero-fill of the mask rows runs on a second stream the
- * handle owns (event fork/join with `hip_stream`, lowest priority), beside the
- * NMS kernels; when yp_run returns, everything is ordered behind `hip_stream`.
+ * For mask outputs beyond the 256 MiB Infinity Cache, yp_run runs the zero-fill
+ * of the mask rows on a second stream the handle owns (event fork/join with
+ * `hip_stream`, lowest priority), beside the NMS kernels; when yp_run returns,
+ * everything is ordered behind `hip_stream`.
  *
  * Experiment knobs (environment, read ONCE in yp_create, never on the launch
  * path): YP_TUNE_MASK_NT=1 (non-temporal mask stores), YP_TUNE_SF_WAVES=<n>
- * (score_filter workgroups per CU the plan assumes), YP_TUNE_FILL_FORK=0|1
- * (zero-fill forks at the start of yp_run / after score_filter (default)).
+ * (score_filter workgroups per CU the plan assumes), YP_TUNE_PREFILL=0|1
+ * (fused / separate mask zero-fill; default by output size), YP_TUNE_FILL_FORK=0|1
+ * (the separate fill forks at the start of yp_run / after score_filter (default)).
  */
 #ifndef YOLACT_POST_H
 #define YOLACT_POST_H
@@ -71,9 +73,10 @@ typedef struct yp_config {
   int32_t use_cropped_mask; /* detection.py:102 (1 in every reference call)            */
   int32_t zero_pad_masks;   /* 1: every mask row >= num_det is written as zeros, which
                                is the reference's tf.zeros layout (detection.py:68);
-                               0: only the rows a detection can land in are written
-                               (rows < min(max_dets, 256), and < top_k in cross-class
-                               mode): zeros from num_det on; later rows are untouched  */
+                               0: rows >= num_det are either untouched or zeros
+                               (zeros where the library pre-fills the rows a
+                               detection can land in: rows < min(max_dets, 256),
+                               and < top_k in cross-class mode)                        */
   float mask_threshold;     /* < 0: float masks only.  >= 0: det_bitmaps = mask > thr
                                (the callers' binarisation, train.py:497)               */
   int32_t max_batch;        /* largest batch yp_run will be given                      */

@@ -14,7 +14,7 @@ PARITY UNPINNED: TensorFlow is not installable in the build container (ordinary
 vectors, known-answer tests or fixtures for this path.  The TF
 op semantics restated here (documented TF behaviour, not captured outputs):
 
-* ``tf.nn.softmax``      -> exp(x - max) / sum            (detection.py:56)
+* ``tf.nn.softmax``      -> exp(x - max) * (1 / sum)      (detection.py:56; Eigen's form)
 * ``tf.boolean_mask``    -> ascending index order kept    (detection.py:73-76)
 * ``tf.math.top_k``      -> descending, ties: lower index first (detection.py:186)
 * ``tf.argmax``          -> first maximum                 (detection.py:184)
@@ -38,10 +38,14 @@ import numpy as np
 
 
 def softmax_lastaxis(x: np.ndarray) -> np.ndarray:
-    """tf.nn.softmax(x, axis=-1) as called at detection.py:56."""
+    """tf.nn.softmax(x, axis=-1) as called at detection.py:56.  TF's CPU kernel (Eigen,
+    SoftmaxEigenImpl) computes exp(x - max) and multiplies by the RECIPROCAL of the sum
+    (SURVEY.md 8c): one rounding more than a true division, which is exactly the 1-ulp class of
+    difference that reorders saturated near-ties - so the stand-in for TF's arithmetic uses TF's form."""
     m = np.max(x, axis=-1, keepdims=True)
     e = np.exp(x - m)
-    return e / np.sum(e, axis=-1, keepdims=True, dtype=x.dtype)
+    one = x.dtype.type(1.0)
+    return e * (one / np.sum(e, axis=-1, keepdims=True, dtype=x.dtype))
 
 
 def top_k_indices(scores: np.ndarray, k: int) -> np.ndarray:

@@ -412,23 +412,34 @@ def test_batches_that_pad_the_xcd_placement(torch_cuda, nb):
     check_vs_c_oracle(torch_cuda, net, shp, mode="cc", top_k=15, max_dets=15, label=f"pad-{nb}")
 
 
-def test_untouched_and_zero_rows_contract(torch_cuda):
-    """include/yolact_post.h, zero_pad_masks = 0: rows in [num_det, fill rows) are zeros, rows beyond the
-    rows a detection can land in keep what the caller had there."""
+@pytest.mark.parametrize("prefill", [0, 1])
+def test_untouched_and_zero_rows_contract(torch_cuda, prefill, monkeypatch):
+    """include/yolact_post.h, zero_pad_masks = 0: rows beyond the rows a detection can land in keep what
+    the caller had there; rows in [num_det, that bound) are zeros when the separate zero-fill ran
+    (YP_TUNE_PREFILL=1, the default for large outputs) and untouched otherwise.  Both zero-fill paths
+    are bit-exact on the detections' rows."""
     import torch
+    from oracle import c_oracle as co
     from yolact_amd import PostConfig, PostProcessor, synth
-    net, shp = synth.make_toy(5)
+    monkeypatch.setenv("YP_TUNE_PREFILL", str(prefill))          # read once, in yp_create
+    net, shp = synth.make_toy(5, batch=9)
     B, A, C = net["pred_cls"].shape
-    pp = PostProcessor(PostConfig(A, C, 12, 12, 64, 64, nms_mode="cc", top_k=15, max_dets=40, max_batch=B))
-    dev = {k: torch.from_numpy(v).cuda() for k, v in net.items()}
-    out = pp.alloc_outputs(B)
-    out["detection_masks"].fill_(7.0)
-    pp.run(dev["pred_offset"], dev["pred_cls"], dev["pred_mask_coef"], dev["priors"], dev["proto_out"], out=out)
-    pp.sync()
-    m, n = out["detection_masks"].cpu().numpy(), out["num_detections"].cpu().numpy()
-    for b in range(B):
-        assert n[b] <= 15 and not m[b, n[b]:15].any() and (m[b, 15:] == 7.0).all()
-    pp.close()
+    for mode in ("cc", "per_class"):
+        pp = PostProcessor(PostConfig(A, C, 12, 12, 64, 64, nms_mode=mode, top_k=15, max_dets=40, max_batch=B))
+        dev = {k: torch.from_numpy(v).cuda() for k, v in net.items()}
+        out = pp.alloc_outputs(B)
+        out["detection_masks"].fill_(7.0)
+        pp.run(dev["pred_offset"], dev["pred_cls"], dev["pred_mask_coef"], dev["priors"], dev["proto_out"], out=out)
+        pp.sync()
+        got = to_numpy(out)
+        compare(got, co.detect(net, shp, top_k=15, nms_mode=mode, max_dets=40), exact_values=True, label=f"prefill{prefill}-{mode}")
+        m, n = got["detection_masks"], got["num_detections"]
+        bound = 15 if mode == "cc" else 40
+        for b in range(B):
+            assert n[b] <= bound and (m[b, bound:] == 7.0).all()
+            tail = m[b, n[b]:bound]
+            assert (not tail.any()) if prefill else (tail == 7.0).all()
+        pp.close()
 
 
 def test_current_device_is_left_alone(torch_cuda):

@@ -89,6 +89,7 @@ static int plan_handle(const yp_config& c, yp_handle* h) {
   h->tune.mask_nt = env_int("YP_TUNE_MASK_NT", 0);
   h->tune.sf_waves = env_int("YP_TUNE_SF_WAVES", 0);
   h->tune.fill_fork = env_int("YP_TUNE_FILL_FORK", 1);
+  h->tune.prefill = env_int("YP_TUNE_PREFILL", -1);
   h->nseg = c.nms_mode == YP_NMS_CROSS_CLASS ? 1 : c.num_classes - 1;
   h->sel_rows = c.max_dets < YP_SORT_MAX ? c.max_dets : YP_SORT_MAX;
   h->lds_stride = (c.num_classes & 1) ? c.num_classes : c.num_classes + 1;   // odd stride: conflict-free rows
@@ -235,6 +236,7 @@ static int run_batch(yp_handle* h, int batch, const float* pred_offset, const fl
                      float* det_masks, uint8_t* det_bitmaps, int32_t* num_det, int32_t* kept_anchor_idx, hipStream_t st,
                      hipStream_t aux, hipEvent_t ev_fork, hipEvent_t ev_join) {
   const bool prof = h->profile != 0;
+  const bool prefill = det_masks && yp_mask_prefill(h, batch);
   auto fork_fill = [&]() -> int {
     YP_HIP(hipEventRecord(ev_fork, st));
     YP_HIP(hipStreamWaitEvent(aux, ev_fork, 0));
@@ -243,17 +245,17 @@ static int run_batch(yp_handle* h, int batch, const float* pred_offset, const fl
     return YP_OK;
   };
   if (prof) YP_HIP(hipEventRecord(h->ev[0], st));
-  if (det_masks && h->tune.fill_fork == 0) { const int rc = fork_fill(); if (rc) return rc; }
+  if (prefill && h->tune.fill_fork == 0) { const int rc = fork_fill(); if (rc) return rc; }
   YP_HIP(yp_launch_score_filter(h, batch, pred_cls, st));
   if (prof) YP_HIP(hipEventRecord(h->ev[1], st));
-  if (det_masks && h->tune.fill_fork != 0) { const int rc = fork_fill(); if (rc) return rc; }
+  if (prefill && h->tune.fill_fork != 0) { const int rc = fork_fill(); if (rc) return rc; }
   YP_HIP(yp_launch_segment_nms(h, batch, pred_offset, priors, pred_mask_coef, det_boxes, det_classes, det_scores, num_det, kept_anchor_idx, st));
   if (prof) YP_HIP(hipEventRecord(h->ev[2], st));
   if (h->cfg.nms_mode == YP_NMS_PER_CLASS)
     YP_HIP(yp_launch_final_select(h, batch, pred_offset, priors, pred_mask_coef, det_boxes, det_classes, det_scores, num_det, kept_anchor_idx, st));
   if (prof) YP_HIP(hipEventRecord(h->ev[3], st));
   if (det_masks) {
-    YP_HIP(hipStreamWaitEvent(st, ev_join, 0));
+    if (prefill) YP_HIP(hipStreamWaitEvent(st, ev_join, 0));
     YP_HIP(yp_launch_mask_assemble(h, batch, proto, num_det, det_masks, det_bitmaps, st));
   }
   if (prof) YP_HIP(hipEventRecord(h->ev[4], st));

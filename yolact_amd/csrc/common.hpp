@@ -116,10 +116,13 @@ struct yp_scratch {
 //   YP_TUNE_SF_WAVES=<n>     score_filter: single-wave workgroups per CU the plan assumes
 //   YP_TUNE_FILL_FORK=0|1    where the mask zero-fill forks off the caller's stream: 0 = at the start of
 //                            yp_run (beside score_filter), 1 = after score_filter (beside the NMS; default)
+//   YP_TUNE_PREFILL=0|1      0: mask_assemble zero-fills its rows itself (pass Z); 1: separate linear
+//                            zero-fill on the handle's second stream; default: by output size (mask.hip)
 struct yp_tune {
   int mask_nt;
   int sf_waves;
   int fill_fork;
+  int prefill;
 };
 
 struct yp_handle {
@@ -187,6 +190,7 @@ hipError_t yp_launch_final_select(const yp_handle* h, int batch, const float* pr
                                   float* det_classes, float* det_scores, int32_t* num_det, int32_t* kept_idx,
                                   hipStream_t st);
 int yp_mask_fill_rows(const yp_handle* h);
+int yp_mask_prefill(const yp_handle* h, int batch);
 hipError_t yp_launch_mask_zero(const yp_handle* h, int batch, float* det_masks, uint8_t* det_bitmaps, hipStream_t st);
 hipError_t yp_launch_mask_assemble(const yp_handle* h, int batch, const float* proto, const int32_t* num_det,
                                    float* det_masks, uint8_t* det_bitmaps, hipStream_t st);

@@ -10,7 +10,8 @@
 // HBM exactly once; the coefficients and crop edges of a detection are wave-uniform and come in
 // through scalar loads.  The dot product is a K-ordered fma chain (YP-MATH) and is only evaluated
 // by waves whose 64 pixels can lie inside the detection's crop box; everything else is zeros, written
-// in bulk by mask_zero_kernel, which does not depend on the NMS and runs beside it (yp_run).
+// in bulk: by pass Z below, or - for outputs beyond the Infinity Cache - by mask_zero_kernel, which
+// does not depend on the NMS and runs beside it on the handle's second stream (yp_run).
 // Output is written [N][P] (pixel-contiguous), which is the reference's final layout.
 #include <stdlib.h>
 #include "common.hpp"
@@ -22,7 +23,8 @@ struct MaskArgs {
   const int32_t* num_det;  // [B]
   float* masks;            // [B,max_dets,P]
   uint8_t* bitmaps;        // [B,max_dets,P] or null
-  int P, pw, max_dets, sel_rows;
+  int P, pw, max_dets, sel_rows, zero_pad;
+  int prezeroed;           // 1: mask_zero_kernel has already zero-filled every row this kernel would
   float mask_threshold;
 };
 
@@ -34,9 +36,10 @@ struct MaskArgs {
 //      coalesced NON-TEMPORAL 16-byte loads (read once, by nobody else: they must not displace the
 //      output lines that live in L2 / Infinity Cache) and transposed through LDS, so that every lane
 //      ends up with its pixel's 32 values in VGPRs;
-//   2. the rows were zero-filled beforehand (mask_zero_kernel); the detections whose crop box can touch
-//      the wave's pixels (one bit each, found with ctz) get the K-ordered fma chain + sigmoid + crop
-//      and are stored over the zeros.
+//   2. the rows are zeros first - either zero-filled beforehand by mask_zero_kernel (outputs beyond
+//      the Infinity Cache) or by this kernel's pass Z (16-byte stores, 1 KiB per wave-instruction);
+//      pass R: the detections whose crop box can touch the wave's pixels (one bit each, found with
+//      ctz) get the K-ordered fma chain + sigmoid + crop and are stored over the zeros.
 // Workgroups of one image are placed on one XCD (the dispatcher deals consecutive workgroup ids
 // round-robin over the 8 XCDs), so the partial cache lines at workgroup borders (mask rows are
 // only 16-byte aligned: P*4 bytes is not a multiple of 128) merge in a single L2.
@@ -92,8 +95,9 @@ __global__ __launch_bounds__(YP_MASK_BLOCK) void mask_assemble_kernel(const Mask
       }
     }
   }
-  // A workgroup none of whose waves is touched by any detection has nothing to read or write.
-  if (__syncthreads_or((rel[0] | rel[1] | rel[2] | rel[3]) != 0ull) == 0) return;
+  // Rows already zero-filled: a workgroup none of whose waves is touched by any detection has
+  // nothing to write.
+  if (p.prezeroed && __syncthreads_or((rel[0] | rel[1] | rel[2] | rel[3]) != 0ull) == 0) return;
 
   float pr[YP_MASK_DIM];
   {
@@ -131,6 +135,43 @@ __global__ __launch_bounds__(YP_MASK_BLOCK) void mask_assemble_kernel(const Mask
   const uint32_t voff = (uint32_t)t * 4u;
   const uint32_t rstride = (uint32_t)p.P * 4u;     // yp_create bounds sel_rows * P * 4 below 2^32
   const bool plain = !NT_STORE && brow == nullptr;
+  //   pass Z  (only when the rows were not zero-filled beforehand) every row gets zeros: one store +
+  //           one vector add per row, nothing scalar but the loop
+  //   pass R  only the rows whose bit is set are computed and stored again, after the zeros have
+  //           been acknowledged (vmcnt(0), plus a barrier where another wave wrote them)
+  const int lane_ = t & 63;
+  const bool wide = plain && (p.P & 3) == 0 && ((uintptr_t)p.masks & 15u) == 0;
+  if (p.prezeroed) {
+    // nothing: the rows are zero already and only the detections that touch this wave are rewritten
+  } else if (wide) {
+    // the workgroup's 256 pixels of a row are 1 KiB: one 16-byte store per lane zeroes a whole row
+    // segment (eight full lines), wave w taking rows w, w+4, ...  The rows are then rewritten by the
+    // waves that own their pixels, so these stores must have completed first.
+    const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
+    if (lane_ < (npx >> 2)) {
+      uint32_t vo = (uint32_t)lane_ * 16u + (uint32_t)wv * rstride;
+      const nat4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
+      const int nz = p.zero_pad ? p.max_dets : N;   // tf.zeros rows of detection.py:68 included
+      for (int n = wv; n < nz; n += YP_MASK_BLOCK / 64, vo += (YP_MASK_BLOCK / 64) * rstride)
+        asm volatile("global_store_dwordx4 %0, %1, %2" ::"v"(vo), "v"(zero4), "s"(orow) : "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  } else if (live) {
+    if (plain) {
+      uint32_t vo = voff;
+      const float zero = 0.0f;
+      for (int n = 0; n < N; ++n, vo += rstride)
+        asm volatile("global_store_dword %0, %1, %2" ::"v"(vo), "v"(zero), "s"(orow) : "memory");
+    } else {
+      for (int n = 0; n < N; ++n) {
+        if (NT_STORE) __builtin_nontemporal_store(0.0f, orow + (size_t)n * p.P + t); else orow[(size_t)n * p.P + t] = 0.0f;
+        if (brow) brow[(size_t)n * p.P + t] = 0.0f > p.mask_threshold ? 1 : 0;               // train.py:497
+      }
+    }
+  }
+  // per-wave zero pass: this wave rewrites its own addresses below; its zeros are acknowledged first
+  if (!p.prezeroed && !wide) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
   for (int g = 0; g < YP_SORT_MAX / 64; ++g) {
     u64 w = g * 64 < N ? rel[g] : 0ull;        // wave-uniform
@@ -160,6 +201,15 @@ __global__ __launch_bounds__(YP_MASK_BLOCK) void mask_assemble_kernel(const Mask
           if (brow) brow[(size_t)n * p.P + t] = v > p.mask_threshold ? 1 : 0;                // train.py:497
         }
       }
+    }
+  }
+  if (p.zero_pad && live && !wide && !p.prezeroed) {   // tf.zeros rows of detection.py:68 (the wide zero pass has written them already)
+    float* const out_img = p.masks + (size_t)b * p.max_dets * p.P;
+    uint8_t* const bit_img = p.bitmaps ? p.bitmaps + (size_t)b * p.max_dets * p.P : nullptr;
+    for (int n = N; n < p.max_dets; ++n) {
+      const size_t o = (size_t)n * p.P + pix;
+      out_img[o] = 0.0f;
+      if (bit_img) bit_img[o] = 0;
     }
   }
 }
@@ -193,6 +243,18 @@ __global__ __launch_bounds__(256) void mask_zero_kernel(void* out, long long P, 
   }
 }
 
+// Does this batch take the separate zero-fill (1) or mask_assemble's fused pass Z (0)?  Masks that
+// fit the 256 MiB Infinity Cache are absorbed there and the fused pass is as fast as a fill and a
+// rewrite pass together are slow (config 2, measured: fused 50 us; fill 42 + rewrite 30, and a fill
+// beside the NMS kernels slows their dependent loads 2-4x: 123 us per step fused, 128 forked after
+// score_filter, 121 forked at the start).  Larger outputs stream to HBM, where the linear fill is the
+// fastest way to write zeros and is long enough to hide the whole NMS chain behind it.
+int yp_mask_prefill(const yp_handle* h, int batch) {
+  if (h->tune.prefill >= 0) return h->tune.prefill != 0;
+  const size_t out_bytes = (size_t)batch * h->cfg.max_dets * h->cfg.proto_h * h->cfg.proto_w * sizeof(float);
+  return out_bytes > ((size_t)256 << 20);
+}
+
 // Rows [0, yp_mask_fill_rows) of every image are zero-filled before mask_assemble runs: every row a
 // detection can land in (and, with zero_pad_masks, the tf.zeros rows of detection.py:68 as well).
 int yp_mask_fill_rows(const yp_handle* h) {
@@ -221,7 +283,8 @@ hipError_t yp_launch_mask_assemble(const yp_handle* h, int batch, const float* p
   a.proto = proto; a.coef = h->s.coef; a.crop = h->s.crop; a.num_det = num_det;
   a.masks = det_masks; a.bitmaps = det_bitmaps;
   a.P = h->cfg.proto_h * h->cfg.proto_w; a.pw = h->cfg.proto_w;
-  a.max_dets = h->cfg.max_dets; a.sel_rows = h->sel_rows;
+  a.max_dets = h->cfg.max_dets; a.sel_rows = h->sel_rows; a.zero_pad = h->cfg.zero_pad_masks;
+  a.prezeroed = yp_mask_prefill(h, batch) ? 1 : 0;
   a.mask_threshold = h->cfg.mask_threshold;
   const int bpi = (a.P + YP_MASK_BLOCK - 1) / YP_MASK_BLOCK;
   const int by_xcd = batch >= 8 ? 1 : 0;
