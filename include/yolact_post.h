@@ -115,6 +115,26 @@ int yp_run(yp_handle* h, int32_t batch,
            int32_t* num_det, int32_t* kept_anchor_idx,
            void* hip_stream);
 
+/* yp_run without a handle and without any allocation.  NO COUNTERPART IN THE REFERENCE: it is for
+ * callers that cannot allocate device memory - code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc.  Same inputs, outputs and results as yp_run (cfg->max_batch is
+ * ignored), but the scratch is a static array of YP_STATIC_SCRATCH_BYTES inside the library's code
+ * object, one copy per GPU, held until the process ends.  A batch whose scratch exceeds the array is
+ * cut into equal chunks of images that are processed one after the other on hip_stream; a
+ * configuration of which a single image does not fit is rejected with YP_EINVAL (per-class mode
+ * needs about 8 * num_anchors * min(num_classes-1, 1/conf_thresh + 1) bytes per image).  It calls no
+ * hipMalloc / hipFree, creates no stream or event (the mask zero-fill, where used, runs on
+ * hip_stream itself) and does not synchronise.  Every call on a GPU uses that GPU's one array: calls
+ * that overlap on one GPU (two streams, two threads) race and give wrong results - serialise them. */
+#define YP_STATIC_SCRATCH_BYTES (64u << 20)
+int yp_run_static(const yp_config* cfg, int32_t batch,
+                  const float* pred_offset, const float* pred_cls, const float* pred_mask_coef,
+                  const float* priors, const float* proto,
+                  float* det_boxes, float* det_classes, float* det_scores,
+                  float* det_masks, uint8_t* det_bitmaps,
+                  int32_t* num_det, int32_t* kept_anchor_idx,
+                  void* hip_stream);
+
 /* Blocks until the handle's last yp_run has finished.  (TF: fetching the tensors.) */
 int yp_sync(yp_handle* h);
 

@@ -14,11 +14,12 @@ LIB_PATH = os.path.join(HERE, "libyolact_post.so")
 YP_NMS_CROSS_CLASS = 0
 YP_NMS_PER_CLASS = 1
 YP_NUM_KERNELS = 4
+YP_STATIC_SCRATCH_BYTES = 64 << 20
 KERNEL_NAMES = ("score_filter", "segment_nms", "final_select", "mask_assemble")
 
 # every symbol include/yolact_post.h declares
 EXPORTS = ("yp_create", "yp_destroy", "yp_run", "yp_sync", "yp_last_survivors", "yp_profile_enable",
-           "yp_profile_read", "yp_scratch_bytes", "yp_last_error", "yp_version", "yp_make_priors")
+           "yp_profile_read", "yp_scratch_bytes", "yp_last_error", "yp_version", "yp_make_priors", "yp_run_static")
 
 
 class YpConfig(ctypes.Structure):
@@ -59,6 +60,8 @@ def load():
     L.yp_destroy.argtypes = [vp]
     L.yp_run.restype = ctypes.c_int
     L.yp_run.argtypes = [vp, ctypes.c_int32] + [vp] * 5 + [vp] * 7 + [vp]
+    L.yp_run_static.restype = ctypes.c_int
+    L.yp_run_static.argtypes = [ctypes.POINTER(YpConfig), ctypes.c_int32] + [vp] * 5 + [vp] * 7 + [vp]
     L.yp_sync.restype = ctypes.c_int
     L.yp_sync.argtypes = [vp]
     L.yp_last_survivors.restype = ctypes.c_int

@@ -6,6 +6,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
 #include <new>
 
 #include "common.hpp"
@@ -238,6 +239,10 @@ static int run_batch(yp_handle* h, int batch, const float* pred_offset, const fl
   const bool prof = h->profile != 0;
   const bool prefill = det_masks && yp_mask_prefill(h, batch);
   auto fork_fill = [&]() -> int {
+    if (!aux) {   // no second stream (the allocation-free entry point): the fill goes first, in stream order
+      YP_HIP(yp_launch_mask_zero(h, batch, det_masks, det_bitmaps, st));
+      return YP_OK;
+    }
     YP_HIP(hipEventRecord(ev_fork, st));
     YP_HIP(hipStreamWaitEvent(aux, ev_fork, 0));
     YP_HIP(yp_launch_mask_zero(h, batch, det_masks, det_bitmaps, aux));
@@ -255,7 +260,7 @@ static int run_batch(yp_handle* h, int batch, const float* pred_offset, const fl
     YP_HIP(yp_launch_final_select(h, batch, pred_offset, priors, pred_mask_coef, det_boxes, det_classes, det_scores, num_det, kept_anchor_idx, st));
   if (prof) YP_HIP(hipEventRecord(h->ev[3], st));
   if (det_masks) {
-    if (prefill) YP_HIP(hipStreamWaitEvent(st, ev_join, 0));
+    if (prefill && aux) YP_HIP(hipStreamWaitEvent(st, ev_join, 0));
     YP_HIP(yp_launch_mask_assemble(h, batch, proto, num_det, det_masks, det_bitmaps, st));
   }
   if (prof) YP_HIP(hipEventRecord(h->ev[4], st));
@@ -278,6 +283,84 @@ extern "C" int yp_run(yp_handle* h, int32_t batch, const float* pred_offset, con
   h->last_batch = batch;
   return run_batch(h, batch, pred_offset, pred_cls, pred_mask_coef, priors, proto, det_boxes, det_classes, det_scores,
                    det_masks, det_bitmaps, num_det, kept_anchor_idx, st, h->aux_stream, h->ev_fork, h->ev_join);
+}
+
+// ---- the allocation-free entry point ----------------------------------------------------------------
+// Scratch of yp_run_static: one array per GPU inside the code object (every device that loads the
+// library holds its own copy, at its own address, until the process ends).  Host code never uses
+// the array's NAME as an address: g_static_ptr[dev] is what hipGetSymbolAddress returned with that
+// device current, and only that pointer is handed to kernels and memsets.
+static __device__ __align__(256) unsigned char scratch[YP_STATIC_SCRATCH_BYTES];
+
+#define YP_STATIC_MAX_DEVICES 64
+static std::mutex g_static_mu;
+static unsigned char* g_static_ptr[YP_STATIC_MAX_DEVICES];    // per device; null = not resolved yet
+static yp_handle g_static_plan[YP_STATIC_MAX_DEVICES];        // host-side plan of the last config seen per device
+static bool g_static_plan_valid[YP_STATIC_MAX_DEVICES];
+
+extern "C" int yp_run_static(const yp_config* cfg, int32_t batch, const float* pred_offset, const float* pred_cls,
+                             const float* pred_mask_coef, const float* priors, const float* proto, float* det_boxes,
+                             float* det_classes, float* det_scores, float* det_masks, uint8_t* det_bitmaps,
+                             int32_t* num_det, int32_t* kept_anchor_idx, void* hip_stream) {
+  if (!cfg) return fail(YP_EINVAL, "yp_run_static: null config");
+  if (batch < 0) return fail(YP_EINVAL, "yp_run_static: negative batch");
+  if (cfg->device_id < 0 || cfg->device_id >= YP_STATIC_MAX_DEVICES)
+    return fail(YP_ENODEV, "yp_run_static: device_id %d outside [0, %d)", cfg->device_id, YP_STATIC_MAX_DEVICES);
+  std::lock_guard<std::mutex> lock(g_static_mu);   // one call at a time plans and launches (calls that OVERLAP on a GPU race on the scratch anyway)
+  const int dev = cfg->device_id;
+  yp_handle* h = &g_static_plan[dev];
+  yp_config want = *cfg;
+  want.max_batch = 1;   // not part of this entry point's contract: any batch is cut to fit
+  if (!g_static_plan_valid[dev] || memcmp(&h->cfg, &want, sizeof(want)) != 0) {
+    g_static_plan_valid[dev] = false;
+    const int rc = plan_handle(want, h);   // validation + host-side plan; queries only, nothing allocated
+    if (rc != YP_OK) return rc;
+    g_static_plan_valid[dev] = true;
+  }
+  const int rc = check_run_args(h, pred_offset, pred_cls, pred_mask_coef, priors, proto, det_boxes, det_classes, det_scores,
+                                det_masks, det_bitmaps, num_det);
+  if (rc != YP_OK) return rc;
+  if (batch == 0) return YP_OK;
+  YP_ON_DEVICE(dev);
+  if (!g_static_ptr[dev]) {   // once per device, with that device current
+    unsigned char* ptr = nullptr;
+    const hipError_t e = hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch));
+    if (e != hipSuccess || !ptr) return fail(YP_EHIP, "hipGetSymbolAddress(scratch) failed on device %d: %s", dev, hipGetErrorString(e));
+    g_static_ptr[dev] = ptr;
+  }
+  unsigned char* const base = g_static_ptr[dev];
+  // the largest chunk of images whose scratch fits the array, then equal chunks
+  const size_t one = scratch_layout(h, 1).total;
+  if (one > (size_t)YP_STATIC_SCRATCH_BYTES)
+    return fail(YP_EINVAL, "yp_run_static: one image of this configuration needs %zu bytes of scratch, the static scratch holds %zu "
+                           "(YP_STATIC_SCRATCH_BYTES); use yp_create / yp_run", one, (size_t)YP_STATIC_SCRATCH_BYTES);
+  int fit = 1;
+  for (int lo = 1, hi = batch; lo <= hi;) {   // scratch grows with the batch: binary search
+    const int mid = lo + (hi - lo) / 2;
+    if (scratch_layout(h, mid).total <= (size_t)YP_STATIC_SCRATCH_BYTES) { fit = mid; lo = mid + 1; } else hi = mid - 1;
+  }
+  const int nchunks = (batch + fit - 1) / fit;
+  const int per = (batch + nchunks - 1) / nchunks;
+  const yp_config& c = h->cfg;
+  const size_t A = (size_t)c.num_anchors, C = (size_t)c.num_classes, P = (size_t)c.proto_h * c.proto_w, R = (size_t)c.max_dets;
+  hipStream_t st = (hipStream_t)hip_stream;
+  for (int lo = 0; lo < batch; lo += per) {
+    const int nb = batch - lo < per ? batch - lo : per;
+    const ScratchLayout L = scratch_layout(h, nb);
+    if (L.total > (size_t)YP_STATIC_SCRATCH_BYTES) return fail(YP_EINVAL, "yp_run_static: internal: chunk of %d images does not fit", nb);
+    carve_scratch(h, L, base, nb);
+    h->cfg.max_batch = nb;
+    // the array keeps the previous call's (or chunk's) contents: the counters start from zero
+    YP_HIP(hipMemsetAsync(h->s.seg_count, 0, L.n_cnt * sizeof(int32_t), st));
+    const int rcb = run_batch(h, nb, pred_offset + lo * A * 4, pred_cls + lo * A * C, pred_mask_coef + lo * A * YP_MASK_DIM, priors,
+                              proto ? proto + lo * P * YP_MASK_DIM : nullptr, det_boxes + lo * R * 4, det_classes + lo * R,
+                              det_scores + lo * R, det_masks ? det_masks + lo * R * P : nullptr,
+                              det_bitmaps ? det_bitmaps + lo * R * P : nullptr, num_det + lo,
+                              kept_anchor_idx ? kept_anchor_idx + lo * R : nullptr, st, nullptr, nullptr, nullptr);
+    h->cfg.max_batch = 1;
+    if (rcb != YP_OK) return rcb;
+  }
+  return YP_OK;
 }
 
 extern "C" int yp_sync(yp_handle* h) {
