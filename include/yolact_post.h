@@ -18,16 +18,11 @@
  * Every entry point leaves the calling thread's current HIP device unchanged.
  * There is no CPU backend: without a HIP device yp_create fails.
  *
- * For mask outputs beyond the 256 MiB Infinity Cache, yp_run runs the zero-fill
- * of the mask rows on a second stream the handle owns (event fork/join with
- * `hip_stream`, lowest priority), beside the NMS kernels; when yp_run returns,
- * everything is ordered behind `hip_stream`.
- *
  * Experiment knobs (environment, read ONCE in yp_create, never on the launch
  * path): YP_TUNE_MASK_NT=1 (non-temporal mask stores), YP_TUNE_SF_WAVES=<n>
  * (score_filter workgroups per CU the plan assumes), YP_TUNE_PREFILL=0|1
- * (fused / separate mask zero-fill; default by output size), YP_TUNE_FILL_FORK=0|1
- * (the separate fill forks at the start of yp_run / after score_filter (default)).
+ * (mask rows zero-filled by mask_assemble itself / by fill workgroups inside the
+ * NMS launch (default)).
  */
 #ifndef YOLACT_POST_H
 #define YOLACT_POST_H
@@ -123,8 +118,7 @@ int yp_run(yp_handle* h, int32_t batch,
  * cut into equal chunks of images that are processed one after the other on hip_stream; a
  * configuration of which a single image does not fit is rejected with YP_EINVAL (per-class mode
  * needs about 8 * num_anchors * min(num_classes-1, 1/conf_thresh + 1) bytes per image).  It calls no
- * hipMalloc / hipFree, creates no stream or event (the mask zero-fill, where used, runs on
- * hip_stream itself) and does not synchronise.  Every call on a GPU uses that GPU's one array: calls
+ * hipMalloc / hipFree, creates no stream or event and does not synchronise.  Every call on a GPU uses that GPU's one array: calls
  * that overlap on one GPU (two streams, two threads) race and give wrong results - serialise them. */
 #define YP_STATIC_SCRATCH_BYTES (64u << 20)
 int yp_run_static(const yp_config* cfg, int32_t batch,
@@ -144,9 +138,9 @@ int yp_last_survivors(yp_handle* h, int32_t* host_out, int32_t batch);
 
 /* Per-kernel timing for benchmarks (no reference counterpart).  When enabled, yp_run brackets
  * each kernel with HIP events on hip_stream; yp_profile_read synchronises and returns the
- * last run's durations in milliseconds: [0] score_filter [1] segment_nms [2] final_select
- * (0 in cross-class mode) [3] mask_assemble. */
-#define YP_NUM_KERNELS 4
+ * last run's durations in milliseconds: [0] score_filter [1] nms (top-k + Fast NMS + final
+ * selection, with the mask zero-fill riding in the same launch) [2] mask_assemble. */
+#define YP_NUM_KERNELS 3
 int yp_profile_enable(yp_handle* h, int32_t on);
 int yp_profile_read(yp_handle* h, float* ms_out /* [YP_NUM_KERNELS] */);
 

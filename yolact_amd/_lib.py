@@ -13,9 +13,9 @@ LIB_PATH = os.path.join(HERE, "libyolact_post.so")
 
 YP_NMS_CROSS_CLASS = 0
 YP_NMS_PER_CLASS = 1
-YP_NUM_KERNELS = 4
+YP_NUM_KERNELS = 3
 YP_STATIC_SCRATCH_BYTES = 64 << 20
-KERNEL_NAMES = ("score_filter", "segment_nms", "final_select", "mask_assemble")
+KERNEL_NAMES = ("score_filter", "nms", "mask_assemble")
 
 # every symbol include/yolact_post.h declares
 EXPORTS = ("yp_create", "yp_destroy", "yp_run", "yp_sync", "yp_last_survivors", "yp_profile_enable",

@@ -89,7 +89,6 @@ static int plan_handle(const yp_config& c, yp_handle* h) {
   h->cfg = c;
   h->tune.mask_nt = env_int("YP_TUNE_MASK_NT", 0);
   h->tune.sf_waves = env_int("YP_TUNE_SF_WAVES", 0);
-  h->tune.fill_fork = env_int("YP_TUNE_FILL_FORK", 1);
   h->tune.prefill = env_int("YP_TUNE_PREFILL", -1);
   h->nseg = c.nms_mode == YP_NMS_CROSS_CLASS ? 1 : c.num_classes - 1;
   h->sel_rows = c.max_dets < YP_SORT_MAX ? c.max_dets : YP_SORT_MAX;
@@ -145,7 +144,7 @@ static ScratchLayout scratch_layout(const yp_handle* h, int max_batch) {
   L.coef = off;  off = align_up(off + B * h->sel_rows * YP_MASK_DIM * sizeof(float), 256);
   L.cnt = off;   // all counters contiguous
   L.max_items = max_items;
-  L.n_cnt = 2 * max_items + B * nseg + B;
+  L.n_cnt = 2 * max_items + B * nseg + 2 * B;
   off = align_up(off + L.n_cnt * sizeof(int32_t), 256);
   L.total = off;
   return L;
@@ -161,6 +160,7 @@ static void carve_scratch(yp_handle* h, const ScratchLayout& L, void* base_ptr, 
   h->s.seg_surv = h->s.seg_count + L.max_items;
   h->s.pool_count = h->s.seg_surv + L.max_items;
   h->s.stat_surv = h->s.pool_count + (size_t)max_batch * h->nseg;
+  h->s.arrive = h->s.stat_surv + max_batch;
 }
 
 extern "C" int yp_create(const yp_config* cfg, yp_handle** out) {
@@ -179,20 +179,10 @@ extern "C" int yp_create(const yp_config* cfg, yp_handle** out) {
     return fail(YP_ENOMEM, "hipMalloc of %zu scratch bytes failed", L.total);
   }
   carve_scratch(h, L, h->scratch_base, cfg->max_batch);
-  int prio_least = 0, prio_greatest = 0;
-  (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
-  bool ok = hipMemset(h->s.seg_count, 0, L.n_cnt * sizeof(int32_t)) == hipSuccess;
-  // the zero-fill's stream: lowest priority, so the NMS workgroups it runs beside are dispatched first
-  ok = ok && hipStreamCreateWithPriority(&h->aux_stream, hipStreamNonBlocking, prio_least) == hipSuccess;
-  ok = ok && hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) == hipSuccess;
-  ok = ok && hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) == hipSuccess;
-  if (!ok) {
-    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
-    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
-    if (h->aux_stream) (void)hipStreamDestroy(h->aux_stream);
+  if (hipMemset(h->s.seg_count, 0, L.n_cnt * sizeof(int32_t)) != hipSuccess) {   // (the arrival counters must start at zero)
     (void)hipFree(h->scratch_base);
     delete h;
-    return fail(YP_EHIP, "creating the handle's stream / events / counters failed");
+    return fail(YP_EHIP, "hipMemset of the counters failed");
   }
   (void)hipDeviceSynchronize();
 #ifdef YP_STAMPS
@@ -208,9 +198,6 @@ extern "C" int yp_destroy(yp_handle* h) {
   DeviceGuard guard_(h->cfg.device_id);
   (void)hipDeviceSynchronize();
   if (h->profile) for (int i = 0; i <= YP_NUM_KERNELS; ++i) (void)hipEventDestroy(h->ev[i]);
-  (void)hipEventDestroy(h->ev_join);
-  (void)hipEventDestroy(h->ev_fork);
-  (void)hipStreamDestroy(h->aux_stream);
   (void)hipFree(h->scratch_base);
   delete h;
   return YP_OK;
@@ -229,41 +216,21 @@ static int check_run_args(const yp_handle* h, const float* pred_offset, const fl
   return YP_OK;
 }
 
-// The launches of one batch.  The mask zero-fill depends on nothing the other kernels compute, so it
-// forks onto `aux` (event fork/join, no allocation) and runs beside the latency-bound NMS kernels,
-// which leave HBM idle; mask_assemble joins it.
+// The launches of one batch: score_filter -> NMS (+ the mask zero-fill as extra workgroups of the same
+// launch: it depends on nothing the NMS computes) -> mask_assemble.
 static int run_batch(yp_handle* h, int batch, const float* pred_offset, const float* pred_cls, const float* pred_mask_coef,
                      const float* priors, const float* proto, float* det_boxes, float* det_classes, float* det_scores,
-                     float* det_masks, uint8_t* det_bitmaps, int32_t* num_det, int32_t* kept_anchor_idx, hipStream_t st,
-                     hipStream_t aux, hipEvent_t ev_fork, hipEvent_t ev_join) {
+                     float* det_masks, uint8_t* det_bitmaps, int32_t* num_det, int32_t* kept_anchor_idx, hipStream_t st) {
   const bool prof = h->profile != 0;
   const bool prefill = det_masks && yp_mask_prefill(h, batch);
-  auto fork_fill = [&]() -> int {
-    if (!aux) {   // no second stream (the allocation-free entry point): the fill goes first, in stream order
-      YP_HIP(yp_launch_mask_zero(h, batch, det_masks, det_bitmaps, st));
-      return YP_OK;
-    }
-    YP_HIP(hipEventRecord(ev_fork, st));
-    YP_HIP(hipStreamWaitEvent(aux, ev_fork, 0));
-    YP_HIP(yp_launch_mask_zero(h, batch, det_masks, det_bitmaps, aux));
-    YP_HIP(hipEventRecord(ev_join, aux));
-    return YP_OK;
-  };
   if (prof) YP_HIP(hipEventRecord(h->ev[0], st));
-  if (prefill && h->tune.fill_fork == 0) { const int rc = fork_fill(); if (rc) return rc; }
   YP_HIP(yp_launch_score_filter(h, batch, pred_cls, st));
   if (prof) YP_HIP(hipEventRecord(h->ev[1], st));
-  if (prefill && h->tune.fill_fork != 0) { const int rc = fork_fill(); if (rc) return rc; }
-  YP_HIP(yp_launch_segment_nms(h, batch, pred_offset, priors, pred_mask_coef, det_boxes, det_classes, det_scores, num_det, kept_anchor_idx, st));
+  YP_HIP(yp_launch_nms(h, batch, pred_offset, priors, pred_mask_coef, det_boxes, det_classes, det_scores, num_det, kept_anchor_idx,
+                       prefill ? det_masks : nullptr, prefill ? det_bitmaps : nullptr, yp_mask_fill_rows(h), st));
   if (prof) YP_HIP(hipEventRecord(h->ev[2], st));
-  if (h->cfg.nms_mode == YP_NMS_PER_CLASS)
-    YP_HIP(yp_launch_final_select(h, batch, pred_offset, priors, pred_mask_coef, det_boxes, det_classes, det_scores, num_det, kept_anchor_idx, st));
+  if (det_masks) YP_HIP(yp_launch_mask_assemble(h, batch, proto, num_det, det_masks, det_bitmaps, st));
   if (prof) YP_HIP(hipEventRecord(h->ev[3], st));
-  if (det_masks) {
-    if (prefill && aux) YP_HIP(hipStreamWaitEvent(st, ev_join, 0));
-    YP_HIP(yp_launch_mask_assemble(h, batch, proto, num_det, det_masks, det_bitmaps, st));
-  }
-  if (prof) YP_HIP(hipEventRecord(h->ev[4], st));
   return YP_OK;
 }
 
@@ -282,7 +249,7 @@ extern "C" int yp_run(yp_handle* h, int32_t batch, const float* pred_offset, con
   h->last_stream = st;
   h->last_batch = batch;
   return run_batch(h, batch, pred_offset, pred_cls, pred_mask_coef, priors, proto, det_boxes, det_classes, det_scores,
-                   det_masks, det_bitmaps, num_det, kept_anchor_idx, st, h->aux_stream, h->ev_fork, h->ev_join);
+                   det_masks, det_bitmaps, num_det, kept_anchor_idx, st);
 }
 
 // ---- the allocation-free entry point ----------------------------------------------------------------
@@ -350,13 +317,14 @@ extern "C" int yp_run_static(const yp_config* cfg, int32_t batch, const float* p
     if (L.total > (size_t)YP_STATIC_SCRATCH_BYTES) return fail(YP_EINVAL, "yp_run_static: internal: chunk of %d images does not fit", nb);
     carve_scratch(h, L, base, nb);
     h->cfg.max_batch = nb;
-    // the array keeps the previous call's (or chunk's) contents: the counters start from zero
+    // the array keeps the previous call's (or chunk's) contents: the counters (the images' arrival
+    // counters among them) start from zero
     YP_HIP(hipMemsetAsync(h->s.seg_count, 0, L.n_cnt * sizeof(int32_t), st));
     const int rcb = run_batch(h, nb, pred_offset + lo * A * 4, pred_cls + lo * A * C, pred_mask_coef + lo * A * YP_MASK_DIM, priors,
                               proto ? proto + lo * P * YP_MASK_DIM : nullptr, det_boxes + lo * R * 4, det_classes + lo * R,
                               det_scores + lo * R, det_masks ? det_masks + lo * R * P : nullptr,
                               det_bitmaps ? det_bitmaps + lo * R * P : nullptr, num_det + lo,
-                              kept_anchor_idx ? kept_anchor_idx + lo * R : nullptr, st, nullptr, nullptr, nullptr);
+                              kept_anchor_idx ? kept_anchor_idx + lo * R : nullptr, st);
     h->cfg.max_batch = 1;
     if (rcb != YP_OK) return rcb;
   }

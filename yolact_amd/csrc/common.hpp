@@ -107,6 +107,7 @@ struct yp_scratch {
   int32_t* stat_surv;   // [max_batch] anchors past the confidence filter, for yp_last_survivors
   u64* pool;            // [max_batch][ngroups][gcap] per-class NMS survivors (per-class mode), dense per class group
   int32_t* pool_count;  // [max_batch][ngroups] (rewritten every run)
+  int32_t* arrive;      // [max_batch] class groups of an image that have finished; zero between launches
   float4* crop;         // [max_batch][sel_rows] (x1,x2,y1,y2) crop edges in proto pixels
   float* coef;          // [max_batch][sel_rows][32] coefficients of the kept detections
 };
@@ -114,14 +115,11 @@ struct yp_scratch {
 // Experiment knobs, read from the environment ONCE, in yp_create (never on the launch path):
 //   YP_TUNE_MASK_NT=1        mask_assemble stores its rows non-temporally
 //   YP_TUNE_SF_WAVES=<n>     score_filter: single-wave workgroups per CU the plan assumes
-//   YP_TUNE_FILL_FORK=0|1    where the mask zero-fill forks off the caller's stream: 0 = at the start of
-//                            yp_run (beside score_filter), 1 = after score_filter (beside the NMS; default)
-//   YP_TUNE_PREFILL=0|1      0: mask_assemble zero-fills its rows itself (pass Z); 1: separate linear
-//                            zero-fill on the handle's second stream; default: by output size (mask.hip)
+//   YP_TUNE_PREFILL=0|1      0: mask_assemble zero-fills its rows itself (pass Z); 1 (default): the zeros
+//                            are written by fill workgroups that ride in the NMS launch
 struct yp_tune {
   int mask_nt;
   int sf_waves;
-  int fill_fork;
   int prefill;
 };
 
@@ -143,8 +141,6 @@ struct yp_handle {
   void* scratch_base;
   int64_t scratch_bytes;
   yp_scratch s;
-  hipStream_t aux_stream;   // the mask zero-fill runs here, beside the NMS kernels on the caller's stream
-  hipEvent_t ev_fork, ev_join;
   hipStream_t last_stream;
   int last_batch;
   int profile;
@@ -181,16 +177,11 @@ long long yp_priors_count(int num_levels, const int32_t* fmap_hw, int num_ratios
 hipError_t yp_launch_make_priors(int img_h, int img_w, int num_levels, const int32_t* fmap_hw, const double* scales,
                                  int num_ratios, const double* sqrt_ratios, float* priors, hipStream_t st);
 hipError_t yp_launch_score_filter(const yp_handle* h, int batch, const float* pred_cls, hipStream_t st);
-hipError_t yp_launch_segment_nms(const yp_handle* h, int batch, const float* pred_offset, const float* priors,
-                                 const float* pred_mask_coef, float* det_boxes,
-                                 float* det_classes, float* det_scores, int32_t* num_det, int32_t* kept_idx,
-                                 hipStream_t st);
-hipError_t yp_launch_final_select(const yp_handle* h, int batch, const float* pred_offset, const float* priors,
-                                  const float* pred_mask_coef, float* det_boxes,
-                                  float* det_classes, float* det_scores, int32_t* num_det, int32_t* kept_idx,
-                                  hipStream_t st);
+hipError_t yp_launch_nms(const yp_handle* h, int batch, const float* pred_offset, const float* priors,
+                         const float* pred_mask_coef, float* det_boxes,
+                         float* det_classes, float* det_scores, int32_t* num_det, int32_t* kept_idx,
+                         float* fill_masks, uint8_t* fill_bitmaps, int fill_rows, hipStream_t st);
 int yp_mask_fill_rows(const yp_handle* h);
 int yp_mask_prefill(const yp_handle* h, int batch);
-hipError_t yp_launch_mask_zero(const yp_handle* h, int batch, float* det_masks, uint8_t* det_bitmaps, hipStream_t st);
 hipError_t yp_launch_mask_assemble(const yp_handle* h, int batch, const float* proto, const int32_t* num_det,
                                    float* det_masks, uint8_t* det_bitmaps, hipStream_t st);

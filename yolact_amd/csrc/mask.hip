@@ -10,8 +10,8 @@
 // HBM exactly once; the coefficients and crop edges of a detection are wave-uniform and come in
 // through scalar loads.  The dot product is a K-ordered fma chain (YP-MATH) and is only evaluated
 // by waves whose 64 pixels can lie inside the detection's crop box; everything else is zeros, written
-// in bulk: by pass Z below, or - for outputs beyond the Infinity Cache - by mask_zero_kernel, which
-// does not depend on the NMS and runs beside it on the handle's second stream (yp_run).
+// in bulk: by the fill workgroups that ride in the NMS launch (nms.hip fill_block; the default), or by
+// pass Z below.
 // Output is written [N][P] (pixel-contiguous), which is the reference's final layout.
 #include <stdlib.h>
 #include "common.hpp"
@@ -24,7 +24,7 @@ struct MaskArgs {
   float* masks;            // [B,max_dets,P]
   uint8_t* bitmaps;        // [B,max_dets,P] or null
   int P, pw, max_dets, sel_rows, zero_pad;
-  int prezeroed;           // 1: mask_zero_kernel has already zero-filled every row this kernel would
+  int prezeroed;           // 1: the NMS launch's fill workgroups have already zero-filled every row this kernel would
   float mask_threshold;
 };
 
@@ -36,8 +36,8 @@ struct MaskArgs {
 //      coalesced NON-TEMPORAL 16-byte loads (read once, by nobody else: they must not displace the
 //      output lines that live in L2 / Infinity Cache) and transposed through LDS, so that every lane
 //      ends up with its pixel's 32 values in VGPRs;
-//   2. the rows are zeros first - either zero-filled beforehand by mask_zero_kernel (outputs beyond
-//      the Infinity Cache) or by this kernel's pass Z (16-byte stores, 1 KiB per wave-instruction);
+//   2. the rows are zeros first - either zero-filled beforehand by the NMS launch's fill workgroups
+//      or by this kernel's pass Z (16-byte stores, 1 KiB per wave-instruction);
 //      pass R: the detections whose crop box can touch the wave's pixels (one bit each, found with
 //      ctz) get the K-ordered fma chain + sigmoid + crop and are stored over the zeros.
 // Workgroups of one image are placed on one XCD (the dispatcher deals consecutive workgroup ids
@@ -72,8 +72,7 @@ __global__ __launch_bounds__(YP_MASK_BLOCK) void mask_assemble_kernel(const Mask
 
   // Which detections can touch this wave's 64 pixels at all?  Lane l tests detection g*64+l against
   // a bounding range of the wave's pixels (a superset test: the per-pixel compares below decide the
-  // values); the ballots give a bit per detection.  Rows of all other detections keep the zeros that
-  // mask_zero_kernel wrote.  Everything wave-uniform is kept in SGPRs on purpose (readfirstlane where
+  // values); the ballots give a bit per detection.  Rows of all other detections are plain zeros.  Everything wave-uniform is kept in SGPRs on purpose (readfirstlane where
   // the compiler cannot prove it), so that walking the bits is scalar work.
   const int lane = t & 63;
   const int w0 = base_pix + __builtin_amdgcn_readfirstlane(t >> 6) * 64, w1 = min(w0 + 63, p.P - 1);
@@ -214,45 +213,15 @@ __global__ __launch_bounds__(YP_MASK_BLOCK) void mask_assemble_kernel(const Mask
   }
 }
 
-// Zero-fill of the mask rows as one linear stream per image (rows 0 .. nz-1 of an image are
-// contiguous): the form in which HBM takes writes fastest (a plain fill reaches 6.8 TB/s on 0.7-1.3 GB).
-// It depends on nothing the NMS computes - nz is a host-side bound on the rows detections can land
-// in - so yp_run issues it on the handle's second stream, beside the latency-bound NMS kernels that
-// leave HBM idle.  ESIZE = bytes per element (4: float masks, 1: bitmaps).  Workgroup (c, b) fills
-// bytes [c*16 KiB, (c+1)*16 KiB) of image b's region.
-template <int ESIZE>
-__global__ __launch_bounds__(256) void mask_zero_kernel(void* out, long long P, int max_dets, int nz) {
-  const int b = blockIdx.y;
-  const long long len = (long long)nz * P * ESIZE;                 // bytes to clear
-  char* const base = reinterpret_cast<char*>(out) + (long long)b * max_dets * P * ESIZE;
-  const long long lo = (long long)blockIdx.x * 16384;
-  if (lo >= len) return;
-  const long long hi = min(lo + 16384, len);
-  if ((((uintptr_t)base) & 15u) == 0) {
-    typedef float nat4 __attribute__((ext_vector_type(4)));
-    const nat4 z = {0.0f, 0.0f, 0.0f, 0.0f};
-    const long long hi16 = hi & ~15ll;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const long long o = lo + ((long long)u * 256 + threadIdx.x) * 16;
-      if (o < hi16) *reinterpret_cast<nat4*>(base + o) = z;
-    }
-    for (long long o = hi16 + threadIdx.x; o < hi; o += 256) base[o] = 0;
-  } else {
-    for (long long o = lo + threadIdx.x; o < hi; o += 256) base[o] = 0;
-  }
-}
-
-// Does this batch take the separate zero-fill (1) or mask_assemble's fused pass Z (0)?  Masks that
-// fit the 256 MiB Infinity Cache are absorbed there and the fused pass is as fast as a fill and a
-// rewrite pass together are slow (config 2, measured: fused 50 us; fill 42 + rewrite 30, and a fill
-// beside the NMS kernels slows their dependent loads 2-4x: 123 us per step fused, 128 forked after
-// score_filter, 121 forked at the start).  Larger outputs stream to HBM, where the linear fill is the
-// fastest way to write zeros and is long enough to hide the whole NMS chain behind it.
+// Does this batch take the separate zero-fill (1: extra workgroups of the NMS launch, nms.hip
+// fill_block) or mask_assemble's fused pass Z (0)?  The linear fill is the form in which HBM takes
+// writes fastest, it does not depend on the NMS, and the NMS workgroups it shares a launch with are
+// latency-bound and leave HBM idle; the fused pass (1 KiB pieces at a row stride) only keeps up while
+// the whole output set lives in the 256 MiB Infinity Cache because the caller rewrites one buffer.
+// The separate fill is the default; the fused pass stays selectable (YP_TUNE_PREFILL=0).
 int yp_mask_prefill(const yp_handle* h, int batch) {
-  if (h->tune.prefill >= 0) return h->tune.prefill != 0;
-  const size_t out_bytes = (size_t)batch * h->cfg.max_dets * h->cfg.proto_h * h->cfg.proto_w * sizeof(float);
-  return out_bytes > ((size_t)256 << 20);
+  (void)batch;
+  return h->tune.prefill >= 0 ? h->tune.prefill != 0 : 1;
 }
 
 // Rows [0, yp_mask_fill_rows) of every image are zero-filled before mask_assemble runs: every row a
@@ -263,18 +232,6 @@ int yp_mask_fill_rows(const yp_handle* h) {
   int rows = h->sel_rows;                                                   // min(max_dets, 256)
   if (c.nms_mode == YP_NMS_CROSS_CLASS && c.top_k < rows) rows = c.top_k;   // N <= k (detection.py:186)
   return rows;
-}
-
-hipError_t yp_launch_mask_zero(const yp_handle* h, int batch, float* det_masks, uint8_t* det_bitmaps, hipStream_t st) {
-  const long long P = (long long)h->cfg.proto_h * h->cfg.proto_w;
-  const int nz = yp_mask_fill_rows(h);
-  const long long region = (long long)nz * P;
-  hipLaunchKernelGGL((mask_zero_kernel<4>), dim3((unsigned)((region * 4 + 16383) / 16384), batch), dim3(256), 0, st,
-                     (void*)det_masks, P, h->cfg.max_dets, nz);
-  if (det_bitmaps)
-    hipLaunchKernelGGL((mask_zero_kernel<1>), dim3((unsigned)((region + 16383) / 16384), batch), dim3(256), 0, st,
-                       (void*)det_bitmaps, P, h->cfg.max_dets, nz);
-  return hipGetLastError();
 }
 
 hipError_t yp_launch_mask_assemble(const yp_handle* h, int batch, const float* proto, const int32_t* num_det,

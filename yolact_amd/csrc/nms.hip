@@ -14,7 +14,12 @@
 //   per-class    group_nms_kernel: 16 workgroups per image, each owning the classes c with
 //                (c-1) % 16 == g; all of a group's candidates are bucketed by class in LDS and
 //                ranked, decoded and suppressed thread-per-candidate;
-//                final_select_kernel: one workgroup per image, cross-class top max_dets
+//                the group that finishes last (arrival counter, agent-scope release/acquire) then
+//                does the image's cross-class top max_dets selection and writes its output rows
+// Both kernels carry the zero-fill of the mask rows as extra workgroups behind the NMS workgroups
+// (fill_block): it depends on nothing the NMS computes, HBM is idle while these latency-bound
+// workgroups wait on their dependent loads, and riding in the same launch costs no second stream,
+// no events and no 1024-thread workgroup waiting for wave slots behind thousands of fill workgroups.
 // The k x k IoU matrix (160 KB at k=200) is never materialised: the reference's reduce_max over the
 // strict upper triangle followed by `<= threshold` is "no higher-ranked box overlaps more than the
 // threshold", evaluated pair by pair.
@@ -22,8 +27,12 @@
 
 #define YP_RADIX_BITS 11
 #define YP_RADIX_BINS (1 << YP_RADIX_BITS)
-#define YP_STAGE_CAP 4096
-#define YP_GROUP_CAP 1024    // candidates of one class group that the thread-per-candidate path takes
+#define YP_STAGE_CAP 4096    // keys the cross-class kernel stages in LDS for its selection
+#define YP_GSTAGE_CAP 2048   // the same for the per-class kernel's final selection (its LDS is kept small: the
+                             // zero-fill workgroups of the same launch are allotted the same LDS and should fit 2 per CU
+                             // beside 2 NMS workgroups)
+#define YP_GROUP_CAP 1024    // thread slots for the candidates of one class group (threads x YP_GROUP_KPT)
+#define YP_GROUP_LDS 768     // candidates of one class group that the thread-per-candidate path holds in LDS
 #define YP_GROUP_THREADS 512
 #define YP_GROUP_KPT (YP_GROUP_CAP / YP_GROUP_THREADS)
 
@@ -46,6 +55,14 @@ struct NmsArgs {
   int32_t* kept_idx;          // [B,max_dets] (nullable)
   int A, nseg, top_k, max_dets, sel_rows, parts, ngroups, gcap;
   long long cap_item;
+  // the mask zero-fill that rides in the same launch (workgroups with blockIdx.x >= nms_blocks)
+  int32_t* arrive;            // [B] class groups of the image that have finished (per-class mode); zero between launches
+  int nms_blocks;             // workgroups that do NMS work: B (cross-class) or B*ngroups (per-class)
+  float* fill_masks;          // [B,max_dets,P] or null: rows [0, fill_rows) of every image get zeros
+  uint8_t* fill_bitmaps;      // [B,max_dets,P] or null
+  long long fill_P;           // proto_h * proto_w
+  int fill_rows, batch;
+
   float nms_thresh, img_h, img_w, proto_h, proto_w;
   int use_crop;
 #ifdef YP_STAMPS
@@ -64,7 +81,7 @@ struct SelectShared {
   u64 key[YP_SORT_MAX];    // result: selected keys, sorted descending
   u64 tmp[YP_SORT_MAX];    // selected keys before sorting
   int rank[YP_SORT_MAX];
-  int hist[YP_RADIX_BINS];
+  int* hist;               // YP_RADIX_BINS ints of LDS, set by the owner (may alias buffers that are idle during a select)
   int wtot[16];
   u64 lo, hi;
   int sel, need, cnt, fill;
@@ -209,7 +226,7 @@ __device__ __forceinline__ int lds_append_slot(int* counter) {
 }
 
 template <int THREADS>
-__device__ int block_sum(int v, int* wtot) {   // wtot: >= THREADS/64 ints of LDS
+__device__ __forceinline__ int block_sum(int v, int* wtot) {   // wtot: >= THREADS/64 ints of LDS
   v = wave_sum(v);
   __syncthreads();
   if ((threadIdx.x & 63) == 0) wtot[threadIdx.x >> 6] = v;
@@ -223,7 +240,7 @@ __device__ int block_sum(int v, int* wtot) {   // wtot: >= THREADS/64 ints of LD
 // Finds the bin that holds the need-th largest of them: sh.sel = bin, sh.need = how many are still
 // to be taken inside that bin, sh.cnt = keys in that bin.  Four barriers.
 template <int THREADS, class Src>
-__device__ void hist_pass(const Src& src, u64 mask, u64 prefix, int shift, u64 dmask, int need, SelectShared& sh) {
+__device__ __forceinline__ void hist_pass(const Src& src, u64 mask, u64 prefix, int shift, u64 dmask, int need, SelectShared& sh) {
   constexpr int BPT = YP_RADIX_BINS / THREADS;   // bins per thread
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
 #pragma unroll
@@ -261,7 +278,7 @@ __device__ void hist_pass(const Src& src, u64 mask, u64 prefix, int shift, u64 d
 // The k-th largest of n unique keys: on return every key with (key & mask) >= prefix is one of the
 // k largest, and exactly k keys satisfy it.  MSB-first, YP_RADIX_BITS bits per pass.
 template <int THREADS, class Src>
-__device__ void radix_select(const Src& src, int k, SelectShared& sh, u64& prefix_out, u64& mask_out) {
+__device__ __forceinline__ void radix_select(const Src& src, int k, SelectShared& sh, u64& prefix_out, u64& mask_out) {
   u64 prefix = 0, mask = 0;
   int need = k;
   for (int hi = 64; hi > 0; hi -= YP_RADIX_BITS) {
@@ -284,7 +301,7 @@ __device__ void radix_select(const Src& src, int k, SelectShared& sh, u64& prefi
 // number of larger keys, counted with broadcast LDS reads - two barriers instead of a sorting network.
 // sh.rank[] must be zero on entry; it is left zero.
 template <int THREADS>
-__device__ void rank_sort_desc(SelectShared& sh, int m) {
+__device__ __forceinline__ void rank_sort_desc(SelectShared& sh, int m) {
   constexpr int G = THREADS / YP_SORT_MAX;
   const int t = threadIdx.x;
   const int j = t % YP_SORT_MAX, g = t / YP_SORT_MAX;
@@ -307,14 +324,15 @@ __device__ void rank_sort_desc(SelectShared& sh, int m) {
 
 // Leaves the k = min(want, n) largest keys of src in sh.key[0..k), descending; returns k.
 // All threads of the workgroup must call it.  Keys are unique and non-zero.  `stage` is an optional
-// LDS buffer of YP_STAGE_CAP keys.
+// LDS buffer of stage_cap keys.
 //   n <= 256: everything is rank-sorted.
 //   else: ONE histogram pass over the 11 bits just below the highest bit in which the keys differ
 //   (found from their min and max) isolates the bin of the k-th key; if the keys above that bin plus
 //   the bin itself are <= 256 (the normal case: the bins are narrow) they are rank-sorted and the
 //   first k are the answer.  Otherwise a full MSB-first radix select runs.
 template <int THREADS, class Src>
-__device__ int select_topk_sorted(const Src& src, int n, int want, SelectShared& sh, u64* stage, unsigned long long* dbg_ = nullptr) {
+__device__ __forceinline__ int select_topk_sorted(const Src& src, int n, int want, SelectShared& sh, u64* stage, int stage_cap,
+                                                  unsigned long long* dbg_ = nullptr) {
 #ifdef YP_STAMPS
 #define SSTAMP(i) do { if (dbg_ && threadIdx.x == 0) dbg_[i] = (unsigned long long)clock64(); } while (0)
 #else
@@ -333,14 +351,14 @@ __device__ int select_topk_sorted(const Src& src, int n, int want, SelectShared&
     });
     m = n;
   } else {
-    const bool staged = stage != nullptr && n <= YP_STAGE_CAP;
+    const bool staged = stage != nullptr && n <= stage_cap;
     u64 lo = ~0ull, hi = 0ull;   // AND / OR of the keys: they differ exactly in the bits of lo ^ hi
     src.template for_each<THREADS>([&](u64 key) {
       lo &= key;
       hi |= key;
       if (staged) {
         const int q = lds_append_slot(&sh.fill);
-        if (q < YP_STAGE_CAP) stage[q] = key;
+        if (q < stage_cap) stage[q] = key;
       }
     });
     SSTAMP(8);
@@ -435,8 +453,10 @@ __device__ __forceinline__ bool tri_pair(int x, int n, int& i, int& j) {
 // coordinates: SURVEY.md A12) and its coefficient row, compacted for mask_assemble (L206).
 // `of`/`pr` are the anchor's offsets and prior, `cf` its 8 x float4 coefficient row: the caller
 // loads them together, in one round trip.
+struct CoefRow { float4 q0, q1, q2, q3, q4, q5, q6, q7; };   // named members: stays in VGPRs (an indexed array went to scratch)
+static_assert(YP_MASK_DIM == 32, "CoefRow holds 32 coefficients");
 __device__ __forceinline__ void emit_row(const NmsArgs& p, int b, int r, float score, int cls, int anchor,
-                                         const float4 bx /* ymin,xmin,ymax,xmax pixels */, const float4* cf) {
+                                         const float4 bx /* ymin,xmin,ymax,xmax pixels */, const CoefRow& cf) {
   float x1, x2, y1, y2;
   yp_sanitize(bx.y, bx.w, p.img_w, false, 0.0f, x1, x2);     // detection.py:126
   yp_sanitize(bx.x, bx.z, p.img_h, false, 0.0f, y1, y2);     // detection.py:127
@@ -456,18 +476,16 @@ __device__ __forceinline__ void emit_row(const NmsArgs& p, int b, int r, float s
   }
   p.crop[(size_t)b * p.sel_rows + r] = cb;
   float4* co = reinterpret_cast<float4*>(p.coef_out + ((size_t)b * p.sel_rows + r) * YP_MASK_DIM);
-#pragma unroll
-  for (int q = 0; q < YP_MASK_DIM / 4; ++q) co[q] = cf[q];
+  co[0] = cf.q0; co[1] = cf.q1; co[2] = cf.q2; co[3] = cf.q3; co[4] = cf.q4; co[5] = cf.q5; co[6] = cf.q6; co[7] = cf.q7;
 }
-__device__ __forceinline__ void load_coef(const NmsArgs& p, int b, int anchor, float4* cf) {
+__device__ __forceinline__ void load_coef(const NmsArgs& p, int b, int anchor, CoefRow& cf) {
   const float4* ci = reinterpret_cast<const float4*>(p.coef_in + ((size_t)b * p.A + anchor) * YP_MASK_DIM);
-#pragma unroll
-  for (int q = 0; q < YP_MASK_DIM / 4; ++q) cf[q] = ci[q];
+  cf.q0 = ci[0]; cf.q1 = ci[1]; cf.q2 = ci[2]; cf.q3 = ci[3]; cf.q4 = ci[4]; cf.q5 = ci[5]; cf.q6 = ci[6]; cf.q7 = ci[7];
 }
 
 // Rows [n, max_dets) of image b: zeros / -1 (detection.py:65-67); num_det (L114).
 template <int THREADS>
-__device__ void finish_image(const NmsArgs& p, int b, int n, int survivors) {
+__device__ __forceinline__ void finish_image(const NmsArgs& p, int b, int n, int survivors) {
   const int t = threadIdx.x;
   for (int r = n + t; r < p.max_dets; r += THREADS) {
     const size_t o = (size_t)b * p.max_dets + r;
@@ -487,7 +505,7 @@ __device__ void finish_image(const NmsArgs& p, int b, int n, int survivors) {
 // flag (threads < k) and its rank among the kept ones in `pos`; `total` = number kept.  ssup[] must
 // be zero.  All threads must call it.
 template <int THREADS>
-__device__ bool fast_nms_keep(const float4* sbox, int* ssup, int* s_wave_cnt, int k, float thr, int& pos, int& total) {
+__device__ __forceinline__ bool fast_nms_keep(const float4* sbox, int* ssup, int* s_wave_cnt, int k, float thr, int& pos, int& total) {
   const int t = threadIdx.x;
   // the k*(k-1)/2 pairs are dealt evenly to the threads: independent iterations, no long column
   const int npairs = tri_count(k);
@@ -514,15 +532,70 @@ __device__ bool fast_nms_keep(const float4* sbox, int* ssup, int* s_wave_cnt, in
   return keep;
 }
 
+// ---- zero-fill of the mask rows (extra workgroups of the NMS launches) -----------------------------
+// Rows [0, fill_rows) of an image are contiguous in [B,max_dets,P]: one linear stream per image, the
+// form in which HBM takes writes fastest.  Chunk `ch` = THREADS * YP_FILL_UNROLL * 16 bytes of the float
+// masks of one image (YP_FILL_UNROLL 16-byte stores per thread, issued back to back: the kernel's LDS
+// footprint allows only 2-3 workgroups per CU, so a workgroup must keep many stores in flight);
+// the chunks of the uint8 bitmaps, if any, follow.
+#ifndef YP_FILL_UNROLL
+#define YP_FILL_UNROLL 16
+#endif
+template <int THREADS>
+__device__ __forceinline__ void fill_region(char* out, long long len, long long img_stride, long long ch, long long cpi) {
+  constexpr long long CH = (long long)THREADS * YP_FILL_UNROLL * 16;
+  const long long b = ch / cpi;
+  char* const base = out + b * img_stride;
+  const long long lo = (ch - b * cpi) * CH;
+  const long long hi = min(lo + CH, len);
+  if ((((uintptr_t)base) & 15u) == 0) {
+    typedef float nat4 __attribute__((ext_vector_type(4)));
+    const nat4 z = {0.0f, 0.0f, 0.0f, 0.0f};
+    const long long hi16 = hi & ~15ll;
+#pragma unroll
+    for (int u = 0; u < YP_FILL_UNROLL; ++u) {
+      const long long o = lo + ((long long)u * THREADS + threadIdx.x) * 16;
+      if (o < hi16) *reinterpret_cast<nat4*>(base + o) = z;
+    }
+    for (long long o = hi16 + threadIdx.x; o < hi; o += THREADS) base[o] = 0;
+  } else {
+    for (long long o = lo + threadIdx.x; o < hi; o += THREADS) base[o] = 0;
+  }
+}
+template <int THREADS>
+__host__ __device__ inline long long fill_chunks_per_image(long long P, int rows, int esize) {
+  return ((long long)rows * P * esize + (long long)THREADS * YP_FILL_UNROLL * 16 - 1) / ((long long)THREADS * YP_FILL_UNROLL * 16);
+}
+template <int THREADS>
+__device__ __forceinline__ void fill_block(const NmsArgs& p, long long ch) {
+  const long long cpi4 = fill_chunks_per_image<THREADS>(p.fill_P, p.fill_rows, 4);
+  const long long n4 = p.fill_masks ? cpi4 * p.batch : 0;
+  if (ch < n4) {
+    fill_region<THREADS>(reinterpret_cast<char*>(p.fill_masks), (long long)p.fill_rows * p.fill_P * 4,
+                         (long long)p.max_dets * p.fill_P * 4, ch, cpi4);
+  } else if (p.fill_bitmaps) {
+    const long long cpi1 = fill_chunks_per_image<THREADS>(p.fill_P, p.fill_rows, 1);
+    if (ch - n4 < cpi1 * p.batch)
+      fill_region<THREADS>(reinterpret_cast<char*>(p.fill_bitmaps), (long long)p.fill_rows * p.fill_P,
+                           (long long)p.max_dets * p.fill_P, ch - n4, cpi1);
+  }
+}
+
 // Cross-class mode: one workgroup per image (detection.py:181-209).
 template <int THREADS>
 __global__ __launch_bounds__(THREADS) void cc_nms_kernel(const NmsArgs p) {
   __shared__ SelectShared sh;
+  __shared__ int s_hist[YP_RADIX_BINS];
   __shared__ u64 stage[YP_STAGE_CAP];
   __shared__ float4 sbox[YP_SORT_MAX];
   __shared__ int ssup[YP_SORT_MAX];
   __shared__ int s_wave_cnt[YP_SORT_MAX / YP_WAVE];
   const int t = threadIdx.x;
+  if ((int)blockIdx.x >= p.nms_blocks) {   // workgroup-uniform
+    fill_block<THREADS>(p, (long long)blockIdx.x - p.nms_blocks);
+    return;
+  }
+  if (t == 0) sh.hist = s_hist;            // (published by the barriers of block_sum below)
   const int b = blockIdx.x;
   STAMP_INIT(0, b);
   STAMP(0);
@@ -537,13 +610,13 @@ __global__ __launch_bounds__(THREADS) void cc_nms_kernel(const NmsArgs p) {
   STAMP(1);
   const PartSrc src{p.cand + (size_t)b * p.parts * p.cap_item, counts, p.parts, p.cap_item, 0, 0, 0};
 #ifdef YP_STAMPS
-  const int k = select_topk_sorted<THREADS>(src, n, p.top_k, sh, stage, dbg_);
+  const int k = select_topk_sorted<THREADS>(src, n, p.top_k, sh, stage, YP_STAGE_CAP, dbg_);
 #else
-  const int k = select_topk_sorted<THREADS>(src, n, p.top_k, sh, stage);       // detection.py:186
+  const int k = select_topk_sorted<THREADS>(src, n, p.top_k, sh, stage, YP_STAGE_CAP);       // detection.py:186
 #endif
   STAMP(2);
   float4 mybox = make_float4(0.f, 0.f, 0.f, 0.f);
-  float4 cf[YP_MASK_DIM / 4];
+  CoefRow cf = {};
   int anchor = 0;
   if (t < YP_SORT_MAX) {
     ssup[t] = 0;
@@ -571,24 +644,48 @@ __global__ __launch_bounds__(THREADS) void cc_nms_kernel(const NmsArgs p) {
 }
 
 // ---- per-class mode -------------------------------------------------------------------------
+// Stores of data that ANOTHER workgroup of the same launch reads (the groups' pooled survivors and
+// their counts, read by the image's last-arriving group): write-through (global_store ... sc1), so
+// that the hand-off needs no agent-scope release - a release writes back every dirty line of the
+// XCD's L2, and with the mask zero-fill running in the same launch that is megabytes per fence
+// (measured: 208 us per launch with release fences against ~50 with write-through stores).
+__device__ __forceinline__ void store_wt(u64* p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void store_wt(int32_t* p, int32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 struct GroupShared {
-  u64 a[YP_GROUP_CAP];          // the group's keys as they arrive; later, per class, the top_k keys in descending order
-  u64 bk[YP_GROUP_CAP];         // keys bucketed by class; later the pooled NMS survivors (final-key format)
-  float4 box[YP_GROUP_CAP];     // decoded boxes, at the positions of `a`
-  unsigned char pcls[YP_GROUP_CAP];   // class of every bucket position
-  unsigned char psup[YP_GROUP_CAP];   // 1 = suppressed by a higher-ranked box of its class
+  // One 24 KiB region with two lives.  During the group's own NMS: a | bk | box.  During a select (the
+  // class-by-class fallback of a large group, and the image's final selection by the last group):
+  // stage | hist, with the fallback's <= 256 sorted boxes in the first 4 KiB of `box`, which neither covers.
+  union {
+    struct {
+      u64 a[YP_GROUP_LDS];          // the group's keys as they arrive; later, per class, the top_k keys in descending order
+      u64 bk[YP_GROUP_LDS];         // keys bucketed by class; later the pooled NMS survivors (final-key format)
+      float4 box[YP_GROUP_LDS];     // decoded boxes, at the positions of `a`
+    };
+    struct {
+      u64 stage[YP_GSTAGE_CAP];     // final selection: the image's pooled survivors
+      int hist[YP_RADIX_BINS];      // radix histogram of a select
+    };
+  };
+  unsigned char pcls[YP_GROUP_LDS];   // class of every bucket position
+  unsigned char psup[YP_GROUP_LDS];   // 1 = suppressed by a higher-ranked box of its class
   SelectShared sh;
   int cls_cnt[256], cls_off[256], cls_fill[256];
   int ssup[YP_SORT_MAX];
   int s_wave_cnt[YP_SORT_MAX / YP_WAVE];
-  int fill, npool;
+  int start[32];                // final selection: exclusive prefix of the groups' pool lengths
+  int fill, npool, last;
 };
+static_assert(YP_GSTAGE_CAP * sizeof(u64) + YP_RADIX_BINS * sizeof(int) <= 2 * YP_GROUP_LDS * sizeof(u64) + YP_GROUP_LDS * sizeof(float4),
+              "stage | hist alias a | bk | box");
+static_assert(YP_GSTAGE_CAP * sizeof(u64) >= 2 * YP_GROUP_LDS * sizeof(u64) + YP_SORT_MAX * sizeof(float4),
+              "hist starts behind the fallback's sorted boxes (box[0..256))");
 
 // Top_k + Fast NMS of ONE class with the whole workgroup (any number of candidates): the path for
 // groups too large for the thread-per-candidate code.  Appends the survivors to pool[base...] and
 // returns their number.  All threads must call it.
 template <int THREADS>
-__device__ int class_nms_blockwide(const NmsArgs& p, int b, int cls, GroupShared& gs, u64* pool, int base) {
+__device__ __forceinline__ int class_nms_blockwide(const NmsArgs& p, int b, int cls, GroupShared& gs, u64* pool, int base) {
   const int t = threadIdx.x;
   SelectShared& sh = gs.sh;
   float4* sbox = gs.box;
@@ -610,7 +707,7 @@ __device__ int class_nms_blockwide(const NmsArgs& p, int b, int cls, GroupShared
     k = min(p.top_k, n);
   } else {
     __syncthreads();   // everybody has read sh.fill
-    k = select_topk_sorted<THREADS>(src, n, p.top_k, sh, nullptr);                // detection.py:217
+    k = select_topk_sorted<THREADS>(src, n, p.top_k, sh, nullptr, 0);             // detection.py:217
   }
   if (t < k) {                                                                          // detection.py:219
     const int a = min(yp_seg_key_anchor(sh.key[t]), p.A - 1);   // (clamp: never index out of bounds)
@@ -621,44 +718,42 @@ __device__ int class_nms_blockwide(const NmsArgs& p, int b, int cls, GroupShared
   const bool keep = fast_nms_keep<THREADS>(sbox, gs.ssup, gs.s_wave_cnt, k, p.nms_thresh, pos, total);
   if (keep) {                                                                           // detection.py:234-239
     const u64 key = sh.key[t];
-    pool[base + pos] = yp_fin_key(yp_key_score(key), yp_seg_key_anchor(key), cls);
+    store_wt(&pool[base + pos], yp_fin_key(yp_key_score(key), yp_seg_key_anchor(key), cls));
   }
   return total;
 }
 
 // Workgroup (g, b): the classes c of image b with (c-1) % ngroups == g (detection.py:217-239).
 template <int THREADS>
-__global__ __launch_bounds__(THREADS) void group_nms_kernel(const NmsArgs p) {
-  static_assert(THREADS * YP_GROUP_KPT >= YP_GROUP_CAP, "every candidate needs a thread slot");
-  __shared__ GroupShared gs;
+__device__ __forceinline__ void group_nms_body(const NmsArgs& p, int b, int g, GroupShared& gs) {
+  static_assert(THREADS * YP_GROUP_KPT >= YP_GROUP_LDS, "every candidate needs a thread slot");
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int g = blockIdx.x, b = blockIdx.y;
   u64* const pool = p.pool + ((size_t)b * p.ngroups + g) * p.gcap;
   STAMP_INIT(0, b * p.ngroups + g);
   STAMP(0);
   // 1. one pass over the image's lists (a few tens of KB, shared by the image's workgroups through
   //    L2): this group's keys into LDS, class histogram on the way
   if (t < 256) { gs.cls_cnt[t] = 0; gs.cls_fill[t] = 0; }
-  if (t == 0) { gs.fill = 0; gs.npool = 0; }
+  if (t == 0) { gs.fill = 0; gs.npool = 0; gs.sh.hist = gs.hist; }
   __syncthreads();
   const PartSrc src{p.cand + (size_t)b * p.parts * p.cap_item, p.seg_count + (size_t)b * p.parts, p.parts, p.cap_item, 0, p.ngroups, g};
   src.template for_each<THREADS>([&](u64 key) {
     const int q = lds_append_slot(&gs.fill);
-    if (q < YP_GROUP_CAP) gs.a[q] = key;
+    if (q < YP_GROUP_LDS) gs.a[q] = key;
     atomicAdd(&gs.cls_cnt[yp_seg_key_class(key)], 1);
   });
   __syncthreads();
   const int m = gs.fill;
   STAMP(1);
   if (m == 0) {
-    if (t == 0) p.pool_count[(size_t)b * p.ngroups + g] = 0;
+    if (t == 0) store_wt(&p.pool_count[(size_t)b * p.ngroups + g], 0);
     return;
   }
-  if (m > YP_GROUP_CAP) {
+  if (m > YP_GROUP_LDS) {
     // too many for LDS: class by class, each with the whole workgroup
     int base = 0;
     for (int c = g + 1; c <= p.nseg; c += p.ngroups) base += class_nms_blockwide<THREADS>(p, b, c, gs, pool, base);
-    if (t == 0) p.pool_count[(size_t)b * p.ngroups + g] = base;
+    if (t == 0) store_wt(&p.pool_count[(size_t)b * p.ngroups + g], base);
     return;
   }
   // 2. class offsets (exclusive prefix over the 256 possible class ids)
@@ -744,19 +839,18 @@ __global__ __launch_bounds__(THREADS) void group_nms_kernel(const NmsArgs p) {
   STAMP(6);
   // 6. the group's survivors, dense, for the cross-class selection (detection.py:234-239)
   const int np = gs.npool;
-  for (int i = t; i < np; i += THREADS) pool[i] = gs.bk[i];
-  if (t == 0) p.pool_count[(size_t)b * p.ngroups + g] = np;
+  for (int i = t; i < np; i += THREADS) store_wt(&pool[i], gs.bk[i]);
+  if (t == 0) store_wt(&p.pool_count[(size_t)b * p.ngroups + g], np);
   STAMP(7);
 }
 
-// Per-class mode: cross-class top max_dets over the pooled survivors (detection.py:242-248).
+// Per-class mode: cross-class top max_dets over the pooled survivors (detection.py:242-248), run by
+// the workgroup of the image's class group that finished last.
 template <int THREADS>
-__global__ __launch_bounds__(THREADS) void final_select_kernel(const NmsArgs p) {
-  __shared__ SelectShared sh;
-  __shared__ u64 stage[YP_STAGE_CAP];
-  __shared__ int start[32];
+__device__ __forceinline__ void final_select_body(const NmsArgs& p, int b, GroupShared& gs) {
+  SelectShared& sh = gs.sh;
+  int* const start = gs.start;
   const int t = threadIdx.x;
-  const int b = blockIdx.x;
   STAMP_INIT(1, b);
   STAMP(0);
   if (t == 0) {
@@ -773,16 +867,16 @@ __global__ __launch_bounds__(THREADS) void final_select_kernel(const NmsArgs p) 
   if (n > 0) {
     const PoolSrc src{p.pool + (size_t)b * p.ngroups * p.gcap, start, p.ngroups, p.gcap};
 #ifdef YP_STAMPS
-    k = select_topk_sorted<THREADS>(src, n, min(p.max_dets, YP_SORT_MAX), sh, stage, dbg_);
+    k = select_topk_sorted<THREADS>(src, n, min(p.max_dets, YP_SORT_MAX), sh, gs.stage, YP_GSTAGE_CAP, dbg_);
 #else
-    k = select_topk_sorted<THREADS>(src, n, min(p.max_dets, YP_SORT_MAX), sh, stage);
+    k = select_topk_sorted<THREADS>(src, n, min(p.max_dets, YP_SORT_MAX), sh, gs.stage, YP_GSTAGE_CAP);
 #endif
     STAMP(2);
     if (t < k) {
       const u64 key = sh.key[t];
       const int anchor = min(yp_fin_key_anchor(key), p.A - 1);
       const float4 pr = p.priors[anchor], of = p.off[(size_t)b * p.A + anchor];
-      float4 cf[YP_MASK_DIM / 4];
+      CoefRow cf;
       load_coef(p, b, anchor, cf);
       emit_row(p, b, t, yp_key_score(key), yp_fin_key_class(key), anchor, yp_decode(pr, of), cf);
     }
@@ -790,6 +884,43 @@ __global__ __launch_bounds__(THREADS) void final_select_kernel(const NmsArgs p) 
   STAMP(3);
   finish_image<THREADS>(p, b, k, survivors);
   STAMP(4);
+}
+
+// Per-class mode, one launch: workgroup b*ngroups + g does class group g of image b; the group of an
+// image that arrives last does the image's final selection; workgroups beyond nms_blocks zero-fill.
+// Hand-off of the groups' pooled survivors (written by other workgroups, possibly on other XCDs) to
+// the last arriver: the bytes are stored write-through (store_wt), every storing wave drains its
+// stores, the workgroup meets at a barrier, one lane adds to the image's counter at agent scope; the
+// workgroup whose add returns ngroups-1 acquires at agent scope (invalidates its CU's L1) and meets at
+// a barrier before any of its waves loads the lists.
+#ifndef YP_GROUP_MIN_WAVES
+#define YP_GROUP_MIN_WAVES 6   // waves per SIMD the register allocation must allow: 6 = three 512-thread workgroups per CU
+                               // (two NMS + one fill; measured per launch at config 2: 66 us at 4, 60 at 6, 61 at 8)
+#endif
+template <int THREADS>
+__global__ __launch_bounds__(THREADS, YP_GROUP_MIN_WAVES) void group_nms_kernel(const NmsArgs p) {
+  if ((int)blockIdx.x >= p.nms_blocks) {   // workgroup-uniform
+    fill_block<THREADS>(p, (long long)blockIdx.x - p.nms_blocks);
+    return;
+  }
+  __shared__ GroupShared gs;
+  const int b = (int)blockIdx.x / p.ngroups, g = (int)blockIdx.x - b * p.ngroups;
+  group_nms_body<THREADS>(p, b, g, gs);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pool stores have completed
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int old = __hip_atomic_fetch_add(&p.arrive[b], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = old == p.ngroups - 1;
+    if (last) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      p.arrive[b] = 0;                               // ready for the next launch (kernel boundary in between)
+    }
+    gs.last = last;
+  }
+  __syncthreads();
+  if (!gs.last) return;
+  final_select_body<THREADS>(p, b, gs);
 }
 
 static NmsArgs make_args(const yp_handle* h, int batch, const float* pred_offset, const float* priors, const float* pred_mask_coef,
@@ -815,23 +946,32 @@ static NmsArgs make_args(const yp_handle* h, int batch, const float* pred_offset
   return a;
 }
 
-hipError_t yp_launch_segment_nms(const yp_handle* h, int batch, const float* pred_offset, const float* priors,
-                                 const float* pred_mask_coef, float* det_boxes,
-                                 float* det_classes, float* det_scores, int32_t* num_det, int32_t* kept_idx,
-                                 hipStream_t st) {
-  const NmsArgs a = make_args(h, batch, pred_offset, priors, pred_mask_coef, det_boxes, det_classes, det_scores, num_det, kept_idx);
-  if (h->cfg.nms_mode == YP_NMS_CROSS_CLASS)
-    hipLaunchKernelGGL((cc_nms_kernel<1024>), dim3(batch), dim3(1024), 0, st, a);
-  else
-    hipLaunchKernelGGL((group_nms_kernel<YP_GROUP_THREADS>), dim3(a.ngroups, batch), dim3(YP_GROUP_THREADS), 0, st, a);
-  return hipGetLastError();
-}
-
-hipError_t yp_launch_final_select(const yp_handle* h, int batch, const float* pred_offset, const float* priors,
-                                  const float* pred_mask_coef, float* det_boxes,
-                                  float* det_classes, float* det_scores, int32_t* num_det, int32_t* kept_idx,
-                                  hipStream_t st) {
-  const NmsArgs a = make_args(h, batch, pred_offset, priors, pred_mask_coef, det_boxes, det_classes, det_scores, num_det, kept_idx);
-  hipLaunchKernelGGL((final_select_kernel<1024>), dim3(batch), dim3(1024), 0, st, a);
+// NMS (both modes; in per-class mode including the final selection) plus, when fill_masks is given,
+// the zero-fill of rows [0, fill_rows) of every image's masks (and bitmaps) as extra workgroups.
+hipError_t yp_launch_nms(const yp_handle* h, int batch, const float* pred_offset, const float* priors,
+                         const float* pred_mask_coef, float* det_boxes,
+                         float* det_classes, float* det_scores, int32_t* num_det, int32_t* kept_idx,
+                         float* fill_masks, uint8_t* fill_bitmaps, int fill_rows, hipStream_t st) {
+  NmsArgs a = make_args(h, batch, pred_offset, priors, pred_mask_coef, det_boxes, det_classes, det_scores, num_det, kept_idx);
+  a.arrive = h->s.arrive;
+  a.fill_masks = fill_masks; a.fill_bitmaps = fill_masks ? fill_bitmaps : nullptr;
+  a.fill_P = (long long)h->cfg.proto_h * h->cfg.proto_w; a.fill_rows = fill_rows; a.batch = batch;
+  if (h->cfg.nms_mode == YP_NMS_CROSS_CLASS) {
+    constexpr int T = 1024;
+    a.nms_blocks = batch;
+    long long nfill = 0;
+    if (a.fill_masks) nfill += fill_chunks_per_image<T>(a.fill_P, fill_rows, 4) * batch;
+    if (a.fill_bitmaps) nfill += fill_chunks_per_image<T>(a.fill_P, fill_rows, 1) * batch;
+    if (a.nms_blocks + nfill > 0x7fffffffll) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((cc_nms_kernel<T>), dim3((unsigned)(a.nms_blocks + nfill)), dim3(T), 0, st, a);
+  } else {
+    constexpr int T = YP_GROUP_THREADS;
+    a.nms_blocks = batch * a.ngroups;
+    long long nfill = 0;
+    if (a.fill_masks) nfill += fill_chunks_per_image<T>(a.fill_P, fill_rows, 4) * batch;
+    if (a.fill_bitmaps) nfill += fill_chunks_per_image<T>(a.fill_P, fill_rows, 1) * batch;
+    if (a.nms_blocks + nfill > 0x7fffffffll) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((group_nms_kernel<T>), dim3((unsigned)(a.nms_blocks + nfill)), dim3(T), 0, st, a);
+  }
   return hipGetLastError();
 }
