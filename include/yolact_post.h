@@ -155,6 +155,50 @@ int64_t yp_make_priors(int32_t img_h, int32_t img_w, int32_t num_levels, const i
                        const double* scales, int32_t num_ratios, const double* aspect_ratios,
                        float* priors, int64_t capacity, int32_t device_id, void* hip_stream);
 
+/* ---- the consumer step after Detect: resize + binarise + run-length encode ----
+ * What every caller of the reference does with detection_masks on the CPU, per detection:
+ *   YP_RESIZE_THEN_THRESHOLD  cv2.resize(mask, (out_w, out_h)) on the float mask, then `> threshold`
+ *                             (coco_eval.py:133-135, infer.py:31-33)
+ *   YP_THRESHOLD_THEN_RESIZE  `mask > threshold` first, astype(uint8), then cv2.resize of the 0/1
+ *                             bytes (train.py:497,503-506)
+ * followed by pycocotools.mask.encode of the Fortran-ordered bitmap (coco_eval.py:135-136,
+ * utils/coco_tools.py:376-388).  cv2.resize = OpenCV INTER_LINEAR, restated (see csrc/rle.hip).
+ *   det_masks [batch,max_dets,mask_h,mask_w] float, num_det [batch] int32: yp_run's outputs (device)
+ *   bitmaps   [batch,max_dets,out_h,out_w] uint8 0/1, row-major; may be NULL
+ *   rle_counts[batch,max_dets,rle_cap] uint32: the uncompressed COCO counts of every detection
+ *             n < num_det[b] - lengths of alternating runs of 0s and 1s in column-major order,
+ *             starting with the 0s (coco_eval.py:91-98 binary_mask_to_rle states exactly this list)
+ *   rle_len   [batch,max_dets] int32: number of counts (0 for rows >= num_det).  Only the first
+ *             rle_cap counts are stored; rle_len > rle_cap tells the caller to retry with more room
+ *             (out_h*out_w + 1 always suffices).
+ * Limits: mask_h <= 512, out_h <= 4096.  Asynchronous on hip_stream; allocates nothing. */
+enum { YP_RESIZE_THEN_THRESHOLD = 0, YP_THRESHOLD_THEN_RESIZE = 1 };
+int yp_masks_to_rle(int32_t device_id, int32_t batch, int32_t max_dets, int32_t mask_h, int32_t mask_w,
+                    const float* det_masks, const int32_t* num_det,
+                    int32_t out_h, int32_t out_w, float threshold, int32_t order,
+                    uint8_t* bitmaps, uint32_t* rle_counts, int32_t* rle_len, int32_t rle_cap,
+                    void* hip_stream);
+
+/* ---- mask assembly of the training loss (FORWARD ONLY, no gradient) ----
+ * loss/loss_yolact.py:239-253 (YOLACTLoss._loss_mask): mask_p = sigmoid(proto_out[i] @ pos_coef^T),
+ * cropped by the positives' prior boxes (pixels, normalised by img_h / img_w at L247-252) with the
+ * same utils.crop as Detect (L253), for every image of the batch in one launch of kernel 4.
+ *   proto [batch,ph,pw,32]   coef [batch,rows,32]   boxes [batch,rows,4] = [ymin,xmin,ymax,xmax] pixels
+ *   num_rows [batch] int32: positives of every image (<= rows <= 256; the loss caps them at 100)
+ *   crop_workspace [batch,rows,4] float: scratch the caller provides (nothing is allocated)
+ *   out_masks [batch,rows,ph,pw]: rows < num_rows[b] = the loss's `_mask_p` (L273), later rows zeros
+ * All device pointers, 16-byte aligned; asynchronous on hip_stream. */
+int yp_assemble_masks(int32_t device_id, int32_t batch, int32_t rows, int32_t proto_h, int32_t proto_w,
+                      int32_t img_h, int32_t img_w, int32_t use_cropped_mask,
+                      const float* proto, const float* coef, const float* boxes, const int32_t* num_rows,
+                      float* crop_workspace, float* out_masks, void* hip_stream);
+
+/* pycocotools' compressed counts string (maskApi.c rleToString, what mask.encode puts in
+ * rle['counts'], coco_eval.py:136-137) of n HOST counts.  Writes at most cap-1 characters and a
+ * terminating NUL to `out`; returns the length the full string has (>= cap: it did not fit), or a
+ * negative YP_E* code.  Pure host code, no device needed. */
+int yp_rle_string(const uint32_t* counts, int32_t n, char* out, int32_t cap);
+
 /* Bytes of device scratch the handle holds. */
 int64_t yp_scratch_bytes(const yp_handle* h);
 

@@ -41,6 +41,8 @@ def lib():
         L.yo_decode.argtypes = [fp, fp, fp]
         L.yo_softmax_row.restype = None
         L.yo_softmax_row.argtypes = [fp, ctypes.c_int, fp]
+        L.yo_loss_masks.restype = None
+        L.yo_loss_masks.argtypes = [ctypes.c_int] * 7 + [fp] * 4
         L.yo_cpu_ok.restype = ctypes.c_int
         if not L.yo_cpu_ok():
             raise RuntimeError("oracle library needs a CPU with FMA")
@@ -84,3 +86,16 @@ def detect(net_outs, img_shape, conf_thresh=0.05, nms_thresh=0.5, top_k=15, nms_
 
 def exp(x: float) -> float:
     return float(lib().yo_exp(ctypes.c_float(x)))
+
+
+def loss_masks(proto, pos_coef, pos_box, img_h, img_w, use_cropped_mask=True):
+    """loss/loss_yolact.py:239-253 for one image: proto [ph,pw,K], pos_coef [n,K], pos_box [n,4] pixels yxyx
+    -> [n,ph,pw] float32."""
+    L = lib()
+    proto = np.ascontiguousarray(proto, np.float32); pos_coef = np.ascontiguousarray(pos_coef, np.float32)
+    pos_box = np.ascontiguousarray(pos_box, np.float32)
+    ph, pw, K = proto.shape
+    n = pos_coef.shape[0]
+    out = np.zeros((n, ph, pw), np.float32)
+    L.yo_loss_masks(n, K, ph, pw, int(img_h), int(img_w), 1 if use_cropped_mask else 0, _p(proto), _p(pos_coef), _p(pos_box), _p(out))
+    return out

@@ -319,6 +319,44 @@ int yo_detect(int batch, int A, int C, int K, int ph, int pw, int img_h, int img
   return 0;
 }
 
+/*
+ * Mask assembly of the training loss, loss/loss_yolact.py:239-253 (forward): for one image
+ *   mask_p = sigmoid(proto @ pos_coef^T)                                   L239-241
+ *   boxes  = pos_prior_box / [img_h, img_w, img_h, img_w]                  L247-252
+ *   mask_p = utils.crop(mask_p, boxes)                                     L253 (utils/utils.py:108-133)
+ * Output [num_pos, ph, pw] (the transpose of L273).  No clip (L257-258 are commented out there).
+ * Same arithmetic contract as detect_image above.
+ */
+void yo_loss_masks(int num_pos, int K, int ph, int pw, int img_h, int img_w, int use_crop, const float* proto,
+                   const float* pos_coef, const float* pos_box, float* out) {
+  const float fH = (float)img_h, fW = (float)img_w, fph = (float)ph, fpw = (float)pw;
+  const size_t P = (size_t)ph * pw;
+  for (int r = 0; r < num_pos; ++r) {
+    const float* bx = pos_box + 4 * (size_t)r;
+    const float nb[4] = { bx[0] / fH, bx[1] / fW, bx[2] / fH, bx[3] / fW };
+    float cx1 = 0, cx2 = fpw, cy1 = 0, cy2 = fph;
+    if (use_crop) {
+      yo_sanitize(nb[1], nb[3], fpw, 1, 1.0f, &cx1, &cx2);
+      yo_sanitize(nb[0], nb[2], fph, 1, 1.0f, &cy1, &cy2);
+    }
+    const float* cf = pos_coef + (size_t)r * K;
+    float* m = out + (size_t)r * P;
+    for (int row = 0; row < ph; ++row)
+      for (int col = 0; col < pw; ++col) {
+        const float* pr = proto + ((size_t)row * pw + col) * K;
+        float acc = 0.0f;
+        for (int k = 0; k < K; ++k) acc = fmaf(pr[k], cf[k], acc);
+        float v = yo_sigmoid(acc);
+        if (use_crop) {
+          float fr = (float)row, fc = (float)col;
+          int inside = (fc >= cx1) && (fc < cx2) && (fr >= cy1) && (fr < cy2);
+          v = v * (inside ? 1.0f : 0.0f);
+        }
+        m[(size_t)row * pw + col] = v;
+      }
+  }
+}
+
 int yo_has_openmp(void) {
 #ifdef _OPENMP
   return 1;

@@ -321,6 +321,21 @@ def detect(
     }
 
 
+def loss_mask_assembly(proto: np.ndarray, pos_coef: np.ndarray, pos_prior_box: np.ndarray, img_h, img_w,
+                       use_cropped_mask: bool = True) -> np.ndarray:
+    """The forward mask assembly of the training loss, loss/loss_yolact.py:239-253, for one image:
+    proto [ph,pw,K], pos_coef [n,K], pos_prior_box [n,4] yxyx pixels -> [n,ph,pw] (L273's transpose)."""
+    dt = proto.dtype
+    mask_p = proto @ pos_coef.T                                                   # L239-240
+    mask_p = (1.0 / (1.0 + np.exp(-mask_p))).astype(dt)                           # L241
+    if use_cropped_mask:
+        b = pos_prior_box
+        boxes = np.stack([b[:, 0] / dt.type(img_h), b[:, 1] / dt.type(img_w),
+                          b[:, 2] / dt.type(img_h), b[:, 3] / dt.type(img_w)], axis=-1)   # L247-252
+        mask_p = crop(mask_p, boxes)                                              # L253
+    return np.transpose(mask_p, (2, 0, 1))
+
+
 # --------------------------------------------------------------------------
 # data/anchor.py (produces `priors`)
 # --------------------------------------------------------------------------

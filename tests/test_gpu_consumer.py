@@ -1,0 +1,170 @@
+"""yp_masks_to_rle + export_detections on a real MI355X against the consumer-step oracle: bitmaps and
+run-length counts bit-exact (byte / integer work), both threshold orders of the reference's callers."""
+import numpy as np
+import pytest
+
+from oracle import consumer_oracle as co
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(masks, num_det, out_hw, order="resize_then_threshold", threshold=0.5, rle_cap=None, bitmaps=True):
+    import torch
+    from yolact_amd import consumer
+    m = torch.from_numpy(np.ascontiguousarray(masks, np.float32)).cuda()
+    n = torch.from_numpy(np.asarray(num_det, np.int32)).cuda()
+    r = consumer.masks_to_rle(m, n, out_hw, threshold=threshold, order=order, bitmaps=bitmaps, rle_cap=rle_cap)
+    torch.cuda.synchronize()
+    return r
+
+
+def _check(masks, num_det, out_hw, order, threshold=0.5, rle_cap=None):
+    r = _run(masks, num_det, out_hw, order, threshold, rle_cap)
+    counts = r["counts"].cpu().numpy().view(np.uint32)
+    lens = r["len"].cpu().numpy()
+    bm = r["bitmaps"].cpu().numpy()
+    ref = co.masks_to_rle(masks, num_det, out_hw[0], out_hw[1], threshold, co.RESIZE_THEN_THRESHOLD if order == "resize_then_threshold" else co.THRESHOLD_THEN_RESIZE)
+    for b in range(masks.shape[0]):
+        for n in range(masks.shape[1]):
+            if n < num_det[b]:
+                rb, rc = ref[b][n]
+                assert np.array_equal(bm[b, n], rb), (b, n, "bitmap", int((bm[b, n] != rb).sum()))
+                assert lens[b, n] == rc.shape[0], (b, n, lens[b, n], rc.shape[0])
+                assert np.array_equal(counts[b, n, :lens[b, n]], rc), (b, n, "counts")
+            else:
+                assert lens[b, n] == 0
+    return r
+
+
+def _blobs(rng, B, N, h, w):
+    """Soft discs and noise: float masks in [0,1] like sigmoid outputs cropped to a box."""
+    yy, xx = np.mgrid[0:h, 0:w]
+    out = np.zeros((B, N, h, w), np.float32)
+    for b in range(B):
+        for n in range(N):
+            cy, cx, r = rng.uniform(0, h), rng.uniform(0, w), rng.uniform(1.0, 1.0 + 0.4 * max(h, w))
+            m = 1.0 / (1.0 + np.exp(-(r - np.hypot(yy - cy, xx - cx))))
+            m = m + rng.normal(0, 0.15, (h, w)) * (rng.random() < 0.5)
+            y1, y2 = sorted(rng.integers(0, h, 2)); x1, x2 = sorted(rng.integers(0, w, 2))
+            box = np.zeros((h, w), bool); box[y1:y2 + 1, x1:x2 + 1] = True
+            out[b, n] = np.clip(m, 0, 1) * box
+    return out
+
+
+@pytest.mark.parametrize("order", ["resize_then_threshold", "threshold_then_resize"])
+def test_known_answer_masks(order):
+    h, w = 6, 5
+    masks = np.zeros((1, 6, h, w), np.float32)
+    masks[0, 1] = 1.0                                     # all one
+    masks[0, 2, 3, 2] = 1.0                               # single pixel
+    masks[0, 3] = (np.add.outer(np.arange(h), np.arange(w)) % 2)   # checkerboard
+    masks[0, 4] = 0.5                                     # exactly the threshold: strict '>' keeps nothing
+    masks[0, 5, :, 0] = 0.9                               # first column set: the encoding starts with a 0
+    r = _check(masks, [6], (h, w), order)                 # identity size: cv2.resize copies
+    counts, lens = r["counts"].cpu().numpy().view(np.uint32), r["len"].cpu().numpy()
+    assert counts[0, 0, :lens[0, 0]].tolist() == [30]
+    assert counts[0, 1, :lens[0, 1]].tolist() == [0, 30]
+    assert counts[0, 2, :lens[0, 2]].tolist() == [2 * h + 3, 1, 30 - 2 * h - 4]
+    assert lens[0, 3] == 26 and counts[0, 4, :lens[0, 4]].tolist() == [30]   # h even: runs merge across the 4 column borders
+    assert counts[0, 5, :lens[0, 5]].tolist() == [0, h, 30 - h]
+    _check(masks, [6], (24, 20), order)                   # 4x enlargement of the same masks
+    _check(masks, [4], (7, 9), order)                     # odd sizes, fewer detections than rows
+    _check(masks, [0], (12, 12), order)                   # no detection at all
+
+
+@pytest.mark.parametrize("order", ["resize_then_threshold", "threshold_then_resize"])
+def test_random_masks_small_sizes(order):
+    rng = np.random.default_rng(11)
+    for case in range(12):
+        h, w = int(rng.integers(2, 40)), int(rng.integers(2, 40))
+        oh, ow = int(rng.integers(h, 4 * h + 3)), int(rng.integers(w, 4 * w + 3))
+        B, N = int(rng.integers(1, 3)), int(rng.integers(1, 6))
+        masks = _blobs(rng, B, N, h, w) if case % 2 else rng.random((B, N, h, w)).astype(np.float32)
+        nd = rng.integers(0, N + 1, B)
+        _check(masks, nd, (oh, ow), order)
+
+
+def test_out_height_around_the_64_row_chunks():
+    rng = np.random.default_rng(12)
+    masks = rng.random((1, 3, 9, 7)).astype(np.float32)
+    for oh in (63, 64, 65, 127, 128, 129):
+        _check(masks, [3], (oh, 33), "resize_then_threshold")
+
+
+def test_counts_capacity_overflow_is_reported_and_retried():
+    import torch
+    from yolact_amd import _lib
+    rng = np.random.default_rng(13)
+    masks = rng.random((1, 2, 16, 16)).astype(np.float32)       # noise: hundreds of runs
+    r = _check(masks, [2], (40, 40), "resize_then_threshold", rle_cap=4)   # the wrapper retries with room
+    assert int(r["len"].max()) > 4
+    # the raw entry point stores only rle_cap counts and reports the true length
+    L = _lib.load()
+    m = torch.from_numpy(masks).cuda(); n = torch.tensor([2], dtype=torch.int32).cuda()
+    counts = torch.full((1, 2, 4), -1, dtype=torch.int32).cuda(); lens = torch.zeros((1, 2), dtype=torch.int32).cuda()
+    assert L.yp_masks_to_rle(0, 1, 2, 16, 16, m.data_ptr(), n.data_ptr(), 40, 40, 0.5, 0, None, counts.data_ptr(), lens.data_ptr(), 4, None) == 0
+    torch.cuda.synchronize()
+    ref = co.masks_to_rle(masks, [2], 40, 40)
+    for k in range(2):
+        assert int(lens[0, k]) == ref[0][k][1].shape[0]
+        assert np.array_equal(counts[0, k].cpu().numpy().view(np.uint32), ref[0][k][1][:4])
+    assert L.yp_masks_to_rle(0, 1, 2, 600, 16, m.data_ptr(), n.data_ptr(), 40, 40, 0.5, 0, None, counts.data_ptr(), lens.data_ptr(), 4, None) == -1
+
+
+@pytest.mark.parametrize("src,dst", [((138, 138), (550, 550)), ((200, 334), (800, 1333))])
+@pytest.mark.parametrize("order", ["resize_then_threshold", "threshold_then_resize"])
+def test_reference_sizes(src, dst, order):
+    """The proto -> image sizes of BASELINE configs 2 and 5 (coco_eval.py:134 resizes to the original
+    image; the network sizes stand in for it)."""
+    rng = np.random.default_rng(14)
+    masks = _blobs(rng, 1, 3, *src)
+    _check(masks, [3], dst, order)
+
+
+def test_end_to_end_detect_to_annotations():
+    """Detect -> export_detections against the oracle chain (Detect oracle -> consumer oracle):
+    coco_eval.py:123-155's dicts, two images with different original sizes."""
+    import torch
+    from oracle import c_oracle
+    from yolact_amd import Detect, consumer, synth
+    net, shp = synth.make_toy(5, batch=2, proto_hw=(18, 22))
+    det = Detect(5, 300, 100, 0.05, 0.5)
+    res = det(net, shp)
+    torch.cuda.synchronize()
+    orig = [(61, 47), (96, 130)]
+    got = consumer.export_detections(res, ["img0", 7], orig)
+    ref_det = c_oracle.detect(net, shp, top_k=15, nms_mode="cc", max_dets=300)
+    ref = co.export_detections(ref_det, ["img0", 7], orig)
+    assert len(got) == len(ref) > 0
+    for g, r in zip(got, ref):
+        assert g == r, (g, r)
+    import json
+    json.dumps(got)                                                  # coco_eval.py:158-159: it must serialise
+
+
+@pytest.mark.parametrize("use_crop", [True, False])
+def test_loss_mask_assembly_forward(use_crop):
+    """loss/loss_yolact.py:239-253 on the device - bit-exact against the C restatement
+    (same arithmetic contract), within 1e-5 of the numpy/libm restatement; rows beyond num_pos are zeros."""
+    import torch
+    from oracle import c_oracle, detect_oracle as po
+    from yolact_amd import consumer
+    rng = np.random.default_rng(21)
+    for (B, rows, ph, pw, H, W) in ((2, 7, 12, 12, 64, 64), (9, 100, 23, 31, 550, 550), (1, 256, 138, 138, 550, 550)):
+        proto = np.maximum(0, rng.normal(0, 1, (B, ph, pw, 32))).astype(np.float32)
+        coef = np.tanh(rng.normal(0, 1, (B, rows, 32))).astype(np.float32)
+        y1 = rng.uniform(-20, H, (B, rows)); x1 = rng.uniform(-20, W, (B, rows))
+        boxes = np.stack([y1, x1, y1 + rng.uniform(-5, H / 2, (B, rows)), x1 + rng.uniform(-5, W / 2, (B, rows))], -1).astype(np.float32)
+        npos = rng.integers(0, rows + 1, B).astype(np.int32); npos[0] = rows
+        got = consumer.assemble_loss_masks(torch.from_numpy(proto).cuda(), torch.from_numpy(coef).cuda(), torch.from_numpy(boxes).cuda(),
+                                           torch.from_numpy(npos).cuda(), (H, W), use_cropped_mask=use_crop)
+        torch.cuda.synchronize()
+        got = got.cpu().numpy()
+        for b in range(B):
+            n = int(npos[b])
+            ref = c_oracle.loss_masks(proto[b], coef[b, :n], boxes[b, :n], H, W, use_crop)
+            assert np.array_equal(got[b, :n].view(np.uint32), ref.view(np.uint32)), (B, rows, b)
+            assert not got[b, n:].any()
+            if b == 0:
+                refn = po.loss_mask_assembly(proto[b], coef[b, :n], boxes[b, :n], H, W, use_crop)
+                assert np.abs(got[b, :n] - refn).max() <= 1e-5

@@ -13,13 +13,16 @@ LIB_PATH = os.path.join(HERE, "libyolact_post.so")
 
 YP_NMS_CROSS_CLASS = 0
 YP_NMS_PER_CLASS = 1
+YP_RESIZE_THEN_THRESHOLD = 0
+YP_THRESHOLD_THEN_RESIZE = 1
 YP_NUM_KERNELS = 3
 YP_STATIC_SCRATCH_BYTES = 64 << 20
 KERNEL_NAMES = ("score_filter", "nms", "mask_assemble")
 
 # every symbol include/yolact_post.h declares
 EXPORTS = ("yp_create", "yp_destroy", "yp_run", "yp_sync", "yp_last_survivors", "yp_profile_enable",
-           "yp_profile_read", "yp_scratch_bytes", "yp_last_error", "yp_version", "yp_make_priors", "yp_run_static")
+           "yp_profile_read", "yp_scratch_bytes", "yp_last_error", "yp_version", "yp_make_priors", "yp_run_static",
+           "yp_masks_to_rle", "yp_rle_string", "yp_assemble_masks")
 
 
 class YpConfig(ctypes.Structure):
@@ -78,6 +81,13 @@ def load():
     L.yp_make_priors.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(ctypes.c_int32),
                                  ctypes.POINTER(ctypes.c_double), ctypes.c_int32, ctypes.POINTER(ctypes.c_double), vp,
                                  ctypes.c_int64, ctypes.c_int32, vp]
+    L.yp_masks_to_rle.restype = ctypes.c_int
+    L.yp_masks_to_rle.argtypes = [ctypes.c_int32] * 5 + [vp, vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_float, ctypes.c_int32,
+                                  vp, vp, vp, ctypes.c_int32, vp]
+    L.yp_assemble_masks.restype = ctypes.c_int
+    L.yp_assemble_masks.argtypes = [ctypes.c_int32] * 8 + [vp] * 6 + [vp]
+    L.yp_rle_string.restype = ctypes.c_int
+    L.yp_rle_string.argtypes = [ctypes.POINTER(ctypes.c_uint32), ctypes.c_int32, ctypes.c_char_p, ctypes.c_int32]
     L.yp_version.restype = ctypes.c_int
     L.yp_version.argtypes = []
     _lib = L

@@ -1,0 +1,134 @@
+"""The consumer step after ``Detect`` on the device (SURVEY.md 8f, F2 + F3).
+
+What the reference's callers do on the CPU with every kept detection - ``cv2.resize`` of the
+``[ph,pw]`` mask to the image size, ``> 0.5``, ``pycocotools.mask.encode``, and the annotation dicts
+they build from it (``coco_eval.py:123-155``, ``infer.py:24-33``, ``train.py:492-515``) - with the
+resize, the threshold and the run-length counting done by ``yp_masks_to_rle`` (``csrc/rle.hip``).
+torch is plumbing (device memory, current stream); there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+
+ORDERS = {"resize_then_threshold": _lib.YP_RESIZE_THEN_THRESHOLD,     # coco_eval.py:134-135, infer.py:32-33
+          "threshold_then_resize": _lib.YP_THRESHOLD_THEN_RESIZE}     # train.py:497,504-505
+
+
+def masks_to_rle(det_masks: torch.Tensor, num_det: torch.Tensor, out_hw, threshold: float = 0.5,
+                 order: str = "resize_then_threshold", bitmaps: bool = False, rle_cap: int | None = None):
+    """Resize + binarise + run-length encode the first ``num_det[b]`` masks of every image.
+
+    det_masks [B,max_dets,ph,pw] float32 and num_det [B] int32 are CUDA tensors (yp_run's outputs).
+    Returns a dict: ``counts`` [B,max_dets,cap] int32 (bit pattern of uint32: uncompressed COCO
+    counts, column-major, zeros first), ``len`` [B,max_dets] int32, ``bitmaps`` [B,max_dets,out_h,out_w]
+    uint8 or None.  If a detection has more runs than ``rle_cap`` the call is repeated once with room
+    for the longest list (that needs one synchronisation; pass a generous ``rle_cap`` to avoid it).
+    """
+    if not det_masks.is_cuda or det_masks.dtype != torch.float32 or det_masks.dim() != 4 or not det_masks.is_contiguous():
+        raise ValueError("det_masks must be a contiguous float32 CUDA tensor [B,max_dets,ph,pw]")
+    B, md, ph, pw = det_masks.shape
+    dev = det_masks.device
+    if num_det.device != dev or num_det.dtype != torch.int32 or tuple(num_det.shape) != (B,) or not num_det.is_contiguous():
+        raise ValueError("num_det must be a contiguous int32 tensor [B] on the masks' device")
+    out_h, out_w = int(out_hw[0]), int(out_hw[1])
+    L = _lib.load()
+    full = out_h * out_w + 1
+    cap = min(full, int(rle_cap) if rle_cap is not None else 8 * out_w + 64)
+    bm = torch.empty((B, md, out_h, out_w), dtype=torch.uint8, device=dev) if bitmaps else None
+    while True:
+        counts = torch.empty((B, md, cap), dtype=torch.int32, device=dev)
+        lens = torch.empty((B, md), dtype=torch.int32, device=dev)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        _lib.check(L.yp_masks_to_rle(dev.index, B, md, ph, pw, det_masks.data_ptr(), num_det.data_ptr(), out_h, out_w,
+                                     float(threshold), ORDERS[order], bm.data_ptr() if bm is not None else None,
+                                     counts.data_ptr(), lens.data_ptr(), cap, ctypes.c_void_p(stream)))
+        need = int(lens.max().item()) if B * md > 0 else 0
+        if need <= cap:
+            return {"counts": counts, "len": lens, "bitmaps": bm, "size": (out_h, out_w)}
+        cap = min(full, need)
+
+
+def rle_string(counts: np.ndarray) -> str:
+    """pycocotools' compressed ``counts`` string of one list of run lengths (host; yp_rle_string)."""
+    c = np.ascontiguousarray(counts).astype(np.uint32, copy=False)
+    n = int(c.shape[0])
+    cap = 7 * n + 1                                  # a count takes at most 7 characters
+    buf = ctypes.create_string_buffer(cap)
+    rc = _lib.load().yp_rle_string(c.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), n, buf, cap)
+    if rc < 0:
+        _lib.check(rc)
+    return buf.value.decode("ascii")
+
+
+def rle_dicts(rle: dict):
+    """Per image, per detection: ``{'size': [h, w], 'counts': str}`` - what ``mask.encode`` returns after
+    the ``.decode('ascii')`` of coco_eval.py:137."""
+    counts = rle["counts"].cpu().numpy().view(np.uint32)
+    lens = rle["len"].cpu().numpy()
+    h, w = rle["size"]
+    return [[{"size": [h, w], "counts": rle_string(counts[b, n, :lens[b, n]])} for n in range(lens.shape[1]) if lens[b, n] > 0]
+            for b in range(lens.shape[0])]
+
+
+def export_detections(result: dict, image_ids, orig_hw, score_thresh: float = 0.05, threshold: float = 0.5):
+    """The annotation list ``coco_eval.py:123-155`` builds from a Detect result (and
+    ``utils/coco_tools.py:728-737`` for the evaluator): per image ``det_num = count_nonzero(scores >
+    0.05)`` rows, ``category_id = int(class)``, ``segmentation`` = the RLE of the mask resized to the
+    image's own (h, w) and thresholded, ``score = float(score)``.  ``_box_pixels`` carries the
+    ``[y1, x1, y2, x2]`` ints of L139-140 (the reference only draws them).  ``orig_hw[b]`` = (h, w) of
+    image b before it was resized for the network."""
+    masks, scores = result["detection_masks"], result["detection_scores"]
+    B = masks.shape[0]
+    det_num = (scores > score_thresh).sum(dim=1).to(torch.int32).contiguous()          # L123
+    n_host = det_num.cpu().numpy()
+    boxes = result["detection_boxes"].cpu().numpy()
+    classes = result["detection_classes"].cpu().numpy()
+    scores_h = scores.cpu().numpy()
+    sizes = {}
+    for b in range(B):
+        sizes.setdefault((int(orig_hw[b][0]), int(orig_hw[b][1])), []).append(b)
+    enc = [None] * B
+    for (h, w), members in sizes.items():            # one launch per distinct image size
+        idx = torch.as_tensor(members, device=masks.device)
+        sub = masks if len(members) == B else masks.index_select(0, idx).contiguous()
+        nd = det_num if len(members) == B else det_num.index_select(0, idx).contiguous()
+        dicts = rle_dicts(masks_to_rle(sub, nd, (h, w), threshold=threshold))
+        for j, b in enumerate(members):
+            enc[b] = dicts[j]
+    annotations = []
+    for b, image_id in enumerate(image_ids):
+        _h, _w = int(orig_hw[b][0]), int(orig_hw[b][1])
+        det_boxes = boxes[b][:n_host[b]] * np.array([_h, _w, _h, _w])                   # L124-125
+        for i in range(int(n_host[b])):
+            _y1, _x1, _y2, _x2 = (int(v) for v in det_boxes[i].astype(int))             # L139-140
+            annotations.append({"image_id": image_id, "category_id": int(classes[b][i]),      # L150-155
+                                "segmentation": enc[b][i], "score": float(scores_h[b][i]),
+                                "_box_pixels": [_y1, _x1, _y2, _x2]})
+    return annotations
+
+
+def assemble_loss_masks(proto: torch.Tensor, pos_coef: torch.Tensor, pos_prior_box: torch.Tensor, num_pos: torch.Tensor,
+                        img_hw, use_cropped_mask: bool = True, out: torch.Tensor | None = None) -> torch.Tensor:
+    """Forward mask assembly of the training loss (``loss/loss_yolact.py:239-253``) for a whole batch:
+    proto [B,ph,pw,32], pos_coef [B,rows,32], pos_prior_box [B,rows,4] yxyx pixels, num_pos [B] int32 ->
+    [B,rows,ph,pw] float32 (rows >= num_pos[b] are zeros).  Forward only: no gradient is recorded."""
+    B, ph, pw, K = proto.shape
+    rows = pos_coef.shape[1]
+    dev = proto.device
+    for name, t, shape, dt in (("proto", proto, (B, ph, pw, 32), torch.float32), ("pos_coef", pos_coef, (B, rows, 32), torch.float32),
+                               ("pos_prior_box", pos_prior_box, (B, rows, 4), torch.float32), ("num_pos", num_pos, (B,), torch.int32)):
+        if not t.is_cuda or t.device != dev or t.dtype != dt or tuple(t.shape) != shape or not t.is_contiguous():
+            raise ValueError(f"{name} must be a contiguous {dt} CUDA tensor of shape {shape}")
+    if out is None:
+        out = torch.empty((B, rows, ph, pw), dtype=torch.float32, device=dev)
+    ws = torch.empty((B, rows, 4), dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    _lib.check(_lib.load().yp_assemble_masks(dev.index, B, rows, ph, pw, int(img_hw[0]), int(img_hw[1]), int(use_cropped_mask),
+                                             proto.data_ptr(), pos_coef.data_ptr(), pos_prior_box.data_ptr(), num_pos.data_ptr(),
+                                             ws.data_ptr(), out.data_ptr(), ctypes.c_void_p(stream)))
+    return out

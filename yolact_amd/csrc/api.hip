@@ -402,4 +402,72 @@ extern "C" int64_t yp_make_priors(int32_t img_h, int32_t img_w, int32_t num_leve
   return n;
 }
 
+extern "C" int yp_masks_to_rle(int32_t device_id, int32_t batch, int32_t max_dets, int32_t mask_h, int32_t mask_w,
+                               const float* det_masks, const int32_t* num_det, int32_t out_h, int32_t out_w, float threshold,
+                               int32_t order, uint8_t* bitmaps, uint32_t* rle_counts, int32_t* rle_len, int32_t rle_cap,
+                               void* hip_stream) {
+  if (!det_masks || !num_det || !rle_counts || !rle_len) return fail(YP_EINVAL, "yp_masks_to_rle: null pointer");
+  if (batch < 0 || max_dets < 1 || mask_h < 1 || mask_w < 1 || out_h < 1 || out_w < 1 || rle_cap < 1)
+    return fail(YP_EINVAL, "yp_masks_to_rle: sizes must be positive");
+  if (order != YP_RESIZE_THEN_THRESHOLD && order != YP_THRESHOLD_THEN_RESIZE) return fail(YP_EINVAL, "yp_masks_to_rle: bad order");
+  int max_src_h, max_out_h;
+  yp_rle_limits(&max_src_h, &max_out_h);
+  if (mask_h > max_src_h || out_h > max_out_h)
+    return fail(YP_EINVAL, "yp_masks_to_rle: mask_h <= %d and out_h <= %d are supported", max_src_h, max_out_h);
+  if (mask_w > 32767 || out_w > 65535 || max_dets > 65535 || batch > 65535) return fail(YP_EINVAL, "yp_masks_to_rle: size out of range");
+  if (batch == 0) return YP_OK;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(YP_ENODEV, "no HIP device available");
+  if (device_id < 0 || device_id >= ndev) return fail(YP_ENODEV, "device_id %d out of range (%d devices)", device_id, ndev);
+  YP_ON_DEVICE(device_id);
+  YP_HIP(yp_launch_mask_rle(batch, max_dets, mask_h, mask_w, det_masks, num_det, out_h, out_w, threshold, order, bitmaps,
+                            rle_counts, rle_len, rle_cap, (hipStream_t)hip_stream));
+  return YP_OK;
+}
+
+extern "C" int yp_assemble_masks(int32_t device_id, int32_t batch, int32_t rows, int32_t proto_h, int32_t proto_w, int32_t img_h,
+                                 int32_t img_w, int32_t use_cropped_mask, const float* proto, const float* coef, const float* boxes,
+                                 const int32_t* num_rows, float* crop_workspace, float* out_masks, void* hip_stream) {
+  if (!proto || !coef || !boxes || !num_rows || !crop_workspace || !out_masks) return fail(YP_EINVAL, "yp_assemble_masks: null pointer");
+  if (batch < 0 || rows < 1 || rows > YP_SORT_MAX) return fail(YP_EINVAL, "yp_assemble_masks: rows must be in [1, %d]", YP_SORT_MAX);
+  if (proto_h < 1 || proto_w < 1 || img_h < 1 || img_w < 1) return fail(YP_EINVAL, "yp_assemble_masks: bad proto/image size");
+  const long long P = (long long)proto_h * proto_w;
+  if (P > (1ll << 28) || (long long)rows * P * 4 + 4096 >= (1ll << 32))
+    return fail(YP_EINVAL, "yp_assemble_masks: %d rows of %lld pixels exceed the 4 GiB of mask rows per image the kernel addresses", rows, P);
+  if ((long long)batch * rows >= (1ll << 31)) return fail(YP_EINVAL, "yp_assemble_masks: batch*rows too large");
+  if ((((uintptr_t)proto | (uintptr_t)coef | (uintptr_t)boxes | (uintptr_t)crop_workspace) & 15u) != 0)
+    return fail(YP_EINVAL, "yp_assemble_masks: proto, coef, boxes and crop_workspace must be 16-byte aligned");
+  if (batch == 0) return YP_OK;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(YP_ENODEV, "no HIP device available");
+  if (device_id < 0 || device_id >= ndev) return fail(YP_ENODEV, "device_id %d out of range (%d devices)", device_id, ndev);
+  YP_ON_DEVICE(device_id);
+  YP_HIP(yp_launch_loss_masks(batch, rows, proto_h, proto_w, img_h, img_w, use_cropped_mask, proto, coef, boxes, num_rows,
+                              crop_workspace, out_masks, (hipStream_t)hip_stream));
+  return YP_OK;
+}
+
+// pycocotools maskApi.c rleToString: every count (from the fourth on: its difference to the count two
+// places before) as little-endian groups of 5 bits, bit 5 = "more groups follow", offset by '0'.
+extern "C" int yp_rle_string(const uint32_t* counts, int32_t n, char* out, int32_t cap) {
+  if (!counts || !out || n < 0 || cap < 1) return fail(YP_EINVAL, "yp_rle_string: bad argument");
+  int len = 0;
+  for (int i = 0; i < n; ++i) {
+    long long x = (long long)counts[i];
+    if (i > 2) x -= (long long)counts[i - 2];
+    bool more = true;
+    while (more) {
+      long long c = x & 0x1f;
+      x >>= 5;
+      more = (c & 0x10) ? x != -1 : x != 0;
+      if (more) c |= 0x20;
+      c += 48;
+      if (len < cap - 1) out[len] = (char)c;
+      ++len;
+    }
+  }
+  out[len < cap - 1 ? len : cap - 1] = 0;
+  return len;
+}
+
 extern "C" int64_t yp_scratch_bytes(const yp_handle* h) { return h ? h->scratch_bytes : 0; }

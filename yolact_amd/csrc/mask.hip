@@ -252,3 +252,41 @@ hipError_t yp_launch_mask_assemble(const yp_handle* h, int batch, const float* p
   else hipLaunchKernelGGL((mask_assemble_kernel<false>), grid, dim3(YP_MASK_BLOCK), 0, st, a, bpi, batch, by_xcd);
   return hipGetLastError();
 }
+
+// ---- the same kernel for the training loss (forward only) ------------------------
+// loss/loss_yolact.py:239-253: sigmoid(proto @ pos_coef^T) cropped by the positives' prior boxes, which
+// arrive in pixels and are normalised by the image size (L247-252) before utils.crop (L253).
+__global__ __launch_bounds__(256) void crop_edges_kernel(const float4* boxes /* [total] ymin,xmin,ymax,xmax pixels */,
+                                                         float4* crop /* [total] x1,x2,y1,y2 proto pixels */, int total,
+                                                         float img_h, float img_w, float proto_h, float proto_w, int use_crop) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const float4 bx = boxes[i];
+  float4 cb;
+  if (use_crop) {
+    const float ny1 = bx.x / img_h, nx1 = bx.y / img_w, ny2 = bx.z / img_h, nx2 = bx.w / img_w;   // L247-252
+    yp_sanitize(nx1, nx2, proto_w, true, 1.0f, cb.x, cb.y);                                        // utils/utils.py:116
+    yp_sanitize(ny1, ny2, proto_h, true, 1.0f, cb.z, cb.w);                                        // utils/utils.py:117
+  } else {
+    cb.x = 0.0f; cb.y = proto_w; cb.z = 0.0f; cb.w = proto_h;
+  }
+  crop[i] = cb;
+}
+
+hipError_t yp_launch_loss_masks(int batch, int rows, int ph, int pw, int img_h, int img_w, int use_crop, const float* proto,
+                                const float* coef, const float* boxes, const int32_t* num_rows, float* crop_ws, float* out_masks,
+                                hipStream_t st) {
+  const int total = batch * rows;
+  hipLaunchKernelGGL(crop_edges_kernel, dim3((total + 255) / 256), dim3(256), 0, st, reinterpret_cast<const float4*>(boxes),
+                     reinterpret_cast<float4*>(crop_ws), total, (float)img_h, (float)img_w, (float)ph, (float)pw, use_crop);
+  MaskArgs a;
+  a.proto = proto; a.coef = coef; a.crop = reinterpret_cast<const float4*>(crop_ws); a.num_det = num_rows;
+  a.masks = out_masks; a.bitmaps = nullptr;
+  a.P = ph * pw; a.pw = pw; a.max_dets = rows; a.sel_rows = rows; a.zero_pad = 1; a.prezeroed = 0;
+  a.mask_threshold = -1.0f;
+  const int bpi = (a.P + YP_MASK_BLOCK - 1) / YP_MASK_BLOCK;
+  const int by_xcd = batch >= 8 ? 1 : 0;
+  const dim3 grid(by_xcd ? 8 * ((batch + 7) / 8) * bpi : batch * bpi);
+  hipLaunchKernelGGL((mask_assemble_kernel<false>), grid, dim3(YP_MASK_BLOCK), 0, st, a, bpi, batch, by_xcd);
+  return hipGetLastError();
+}
