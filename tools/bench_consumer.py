@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Times the consumer step (resize + binarise + RLE) on Detect's outputs at BASELINE
+config 2 (32 images x 100 detections, 138x138 -> 550x550), and - as the CPU comparison - the numpy
+restatement of what the reference's callers do per detection (cv2.resize + threshold + encode) on a
+bounded sample.  Prints one JSON line.  Not the headline bench (that is bench.py)."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    import torch
+    from yolact_amd import PostConfig, PostProcessor, consumer, synth
+    cfg = synth.CONFIGS[2]
+    B = cfg.batch
+    net, shp = synth.make_batch(cfg, batch=B)
+    A, C = net["pred_cls"].shape[1:]
+    ph, pw = net["proto_out"].shape[1:3]
+    pp = PostProcessor(PostConfig(A, C, ph, pw, cfg.img_h, cfg.img_w, conf_thresh=cfg.conf_thresh, nms_mode="per_class",
+                                  top_k=cfg.top_k, max_dets=cfg.max_dets, max_batch=B))
+    d = {k: torch.from_numpy(v).cuda() for k, v in net.items()}
+    out = pp.run(d["pred_offset"], d["pred_cls"], d["pred_mask_coef"], d["priors"], d["proto_out"])
+    torch.cuda.synchronize()
+    res = {}
+    for order in ("resize_then_threshold", "threshold_then_resize"):
+        for bitmaps in (False, True):
+            cap = cfg.img_h * cfg.img_w + 1 if order == "resize_then_threshold" else 8 * cfg.img_w
+            r = consumer.masks_to_rle(out["detection_masks"], out["num_detections"], (cfg.img_h, cfg.img_w), order=order,
+                                      bitmaps=bitmaps, rle_cap=20000)
+            torch.cuda.synchronize()
+            cap = int(r["counts"].shape[2])
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                consumer.masks_to_rle(out["detection_masks"], out["num_detections"], (cfg.img_h, cfg.img_w), order=order,
+                                      bitmaps=bitmaps, rle_cap=cap)
+            e1.record(); torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 10
+            ndet = int(out["num_detections"].sum())
+            res[f"{order}{'+bitmaps' if bitmaps else ''}"] = {
+                "ms_per_batch": round(ms, 4), "detections": ndet, "detections_per_s": round(ndet / ms * 1e3, 1),
+                "output_pixels_per_s": round(ndet * cfg.img_h * cfg.img_w / ms * 1e3, 1), "max_runs": int(r["len"].max())}
+    # CPU: the numpy restatement of cv2.resize + threshold + rleEncode, per detection, on 16 detections
+    from oracle import consumer_oracle as co
+    m = out["detection_masks"][0, :16].cpu().numpy()
+    t0 = time.perf_counter()
+    for i in range(16):
+        co.rle_counts(co.mask_to_bitmap(m[i], cfg.img_h, cfg.img_w))
+    t = time.perf_counter() - t0
+    res["cpu_numpy_restatement"] = {"detections_per_s": round(16 / t, 1), "sample": "16 detections, one core"}
+    print(json.dumps({"workload": "config 2: 32 images x 100 detections, 138x138 -> 550x550", **res}))
+
+
+if __name__ == "__main__":
+    main()

@@ -72,4 +72,17 @@ for k, v in sq.items():
     if "rocclr" in k:
         continue
     print(f"- {k}: " + ", ".join(f"{c}={sum(x)/len(x):.3g}" for c, x in sorted(v.items())))
-json.dump({"avg_ns": avg_ns, "traffic": traffic}, open(f"{out}/summary.json", "w"), indent=1)
+
+
+def logical(name):
+    for key, val in (("score_filter_kernel", "score_filter"), ("group_nms_kernel", "nms"), ("cc_nms_kernel", "nms"),
+                     ("mask_assemble_kernel", "mask_assemble"), ("mask_rle_kernel", "mask_rle")):
+        if key in name:
+            return val
+    return None
+
+
+kernels_us = {logical(k): v / 1e3 for k, v in avg_ns.items() if logical(k)}
+traffic_bytes = {logical(k): v["traffic_bytes"] for k, v in traffic.items() if logical(k)}
+json.dump({"avg_ns": avg_ns, "kernels_us": kernels_us, "traffic": traffic, "traffic_bytes": traffic_bytes},
+          open(f"{out}/summary.json", "w"), indent=1)

@@ -60,6 +60,31 @@ __device__ __forceinline__ float yp_exp_t(float x) {
   return y * __builtin_bit_cast(float, (uint32_t)(n + 127) << 23);
 }
 
+// Two exponentials of non-positive arguments at once, on gfx950's packed fp32 pipe (v_pk_fma_f32,
+// v_pk_mul_f32, v_pk_add_f32): each half is the same sequence of IEEE operations as yp_exp_t<true>, so the
+// bits are those of two scalar calls; the instruction count is ~55 % of theirs.
+typedef float yp_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ yp_f2 yp_exp2_le0(yp_f2 x) {
+  x.x = fmaxf(x.x, -87.0f);
+  x.y = fmaxf(x.y, -87.0f);
+  const yp_f2 t = __builtin_elementwise_fma(x, (yp_f2){1.44269504088896341f, 1.44269504088896341f}, (yp_f2){0.5f, 0.5f});
+  const yp_f2 fx = {floorf(t.x), floorf(t.y)};
+  yp_f2 r = __builtin_elementwise_fma(fx, (yp_f2){-0.693359375f, -0.693359375f}, x);
+  r = __builtin_elementwise_fma(fx, (yp_f2){2.12194440e-4f, 2.12194440e-4f}, r);
+  const yp_f2 z = r * r;
+  yp_f2 y = {1.9875691500E-4f, 1.9875691500E-4f};
+  y = __builtin_elementwise_fma(y, r, (yp_f2){1.3981999507E-3f, 1.3981999507E-3f});
+  y = __builtin_elementwise_fma(y, r, (yp_f2){8.3334519073E-3f, 8.3334519073E-3f});
+  y = __builtin_elementwise_fma(y, r, (yp_f2){4.1665795894E-2f, 4.1665795894E-2f});
+  y = __builtin_elementwise_fma(y, r, (yp_f2){1.6666665459E-1f, 1.6666665459E-1f});
+  y = __builtin_elementwise_fma(y, r, (yp_f2){5.0000001201E-1f, 5.0000001201E-1f});
+  y = __builtin_elementwise_fma(y, z, r);
+  y = y + (yp_f2){1.0f, 1.0f};
+  const int nx = (int)fx.x, ny = (int)fx.y;
+  const yp_f2 sc = {__builtin_bit_cast(float, (uint32_t)(nx + 127) << 23), __builtin_bit_cast(float, (uint32_t)(ny + 127) << 23)};
+  return y * sc;
+}
+
 __device__ __forceinline__ float yp_exp(float x) { return yp_exp_t<false>(x); }
 __device__ __forceinline__ float yp_exp_le0(float x) { return yp_exp_t<true>(x); }   // caller guarantees x <= 0
 
