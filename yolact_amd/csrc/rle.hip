@@ -14,13 +14,15 @@
 //      by all threads: one global round trip per batch instead of one per column;
 //   A  a column's source columns sx, sx+1 and weights are wave-uniform: the wave builds the
 //      horizontally interpolated source column (mask_h values) in LDS - exactly OpenCV's row buffer;
-//   B  64 output rows at a time: two LDS reads, the vertical interpolation (per-lane row indices and
-//      weights live in registers), the threshold, one ballot -> 64 bits of the bitmap.  Run boundaries
-//      are the set bits of m ^ (m << 1 | carry): counting and locating them is popcount / clz;
-//   C  after a barrier every wave scans the batch's per-column boundary counts (one lane per column)
-//      and so knows how many boundaries precede its columns and where the last one was; it writes its
-//      run lengths straight to their final places: count j = position of boundary j minus position
-//      of boundary j-1.  No second pass, no atomics.
+//   B  64 output rows at a time: two LDS reads, the vertical interpolation (row indices and weights from
+//      an LDS table), the threshold, one ballot -> 64 bits of the bitmap; nothing else
+//      (the CU's scalar unit is shared by all its waves: per-chunk mask arithmetic there was what bound
+//      the first version of this kernel);
+//   C  after a barrier, one THREAD per (column, 64-row chunk) cell: run boundaries are the set bits of
+//      m ^ (m << 1 | bit before), counted with popcount; a workgroup-wide scan gives every cell the
+//      number of boundaries before it and the position of the last one, and the cell writes its run
+//      lengths straight to their final places: count j = position of boundary j minus position of
+//      boundary j-1.  No second pass, no atomics.
 // HBM traffic is the source mask (once) plus the counts (and the optional bitmap): the kernel is
 // bound by instruction issue.
 #include "common.hpp"
@@ -29,7 +31,6 @@
 #define YP_RLE_WAVES (YP_RLE_THREADS / YP_WAVE)
 #define YP_RLE_MAX_COLS 64        // columns per batch (one lane per column in phase C)
 #define YP_RLE_CELLS 1024         // 64-row chunks of bitmap a batch holds in LDS: ncols * ceil(out_h/64) <= this
-#define YP_RLE_FAST_HB 16         // out_h <= 1024: per-lane vertical coefficients in registers
 #define YP_RLE_MAX_SRC_H 512
 #define YP_RLE_MAX_OUT_H 4096
 #define YP_RLE_SRC_FLOATS 10240   // staged source sub-block (40 KiB at most)
@@ -73,10 +74,8 @@ __device__ __forceinline__ int wave_incl_max(int v, int lane) {
 //   src   [ph][ws] float            staged source sub-block
 //   hcol  [16][ph] float|int        OpenCV's row buffer, one per wave
 //   bits  [YP_RLE_CELLS] u64        the batch's bitmap, [column][chunk]
-//   trans [YP_RLE_CELLS] u64        its run boundaries (a column's first pixel excluded)
-//   col_* [64] int                  per column: first bit, last bit, inner boundary count, last inner boundary position
-//   fy/sy [out_h]                   vertical coefficients (only when out_h > 1024)
-template <bool FAST>
+//   wsum, wmax [16] int             the scan's per-wave totals
+//   fy/sy [out_h]                   vertical coefficients
 __global__ __launch_bounds__(YP_RLE_THREADS) void mask_rle_kernel(const RleArgs p) {
   extern __shared__ __align__(16) char rle_lds[];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -91,12 +90,9 @@ __global__ __launch_bounds__(YP_RLE_THREADS) void mask_rle_kernel(const RleArgs 
   float* const s_src = reinterpret_cast<float*>(lp_);                 lp_ += (size_t)((p.ph * p.ws * 4 + 15) & ~15);
   float* const s_hcol = reinterpret_cast<float*>(lp_) + wave * p.ph;  lp_ += (size_t)((YP_RLE_WAVES * p.ph * 4 + 15) & ~15);
   u64* const s_bits = reinterpret_cast<u64*>(lp_);                    lp_ += YP_RLE_CELLS * 8;
-  u64* const s_trans = reinterpret_cast<u64*>(lp_);                   lp_ += YP_RLE_CELLS * 8;
-  int* const s_first = reinterpret_cast<int*>(lp_);                   lp_ += YP_RLE_MAX_COLS * 4;
-  int* const s_lastbit = reinterpret_cast<int*>(lp_);                 lp_ += YP_RLE_MAX_COLS * 4;
-  int* const s_count = reinterpret_cast<int*>(lp_);                   lp_ += YP_RLE_MAX_COLS * 4;
-  int* const s_lastpos = reinterpret_cast<int*>(lp_);                 lp_ += YP_RLE_MAX_COLS * 4;
-  float* const s_fy = reinterpret_cast<float*>(lp_);                  lp_ += FAST ? 0 : (size_t)p.out_h * 4;
+  int* const s_wsum = reinterpret_cast<int*>(lp_);                    lp_ += YP_RLE_WAVES * 4;
+  int* const s_wmax = reinterpret_cast<int*>(lp_);                    lp_ += YP_RLE_WAVES * 4;
+  float* const s_fy = reinterpret_cast<float*>(lp_);                  lp_ += (size_t)p.out_h * 4;
   short* const s_sy = reinterpret_cast<short*>(lp_);
   int* const s_hcol_i = reinterpret_cast<int*>(s_hcol);
 
@@ -108,30 +104,17 @@ __global__ __launch_bounds__(YP_RLE_THREADS) void mask_rle_kernel(const RleArgs 
   const float one = 1.0f, cscale = 2048.0f;                      // INTER_RESIZE_COEF_SCALE
   const int phm1 = p.ph - 1;
 
-  // vertical coefficients of this lane's output rows (weights kept, row indices clipped at use):
-  // both clipped row indices packed in one register, the fractional weight in another
-  int vr[YP_RLE_FAST_HB];
-  float vf[YP_RLE_FAST_HB];
-  if (FAST) {
-#pragma unroll
-    for (int c = 0; c < YP_RLE_FAST_HB; ++c) {
-      const int y = c * 64 + lane;
-      float f = (float)(((double)y + 0.5) * p.scale_y - 0.5);
-      const int s = (int)floorf(f);
-      vf[c] = f - (float)s;
-      vr[c] = min(max(s, 0), phm1) | (min(max(s + 1, 0), phm1) << 16);
-    }
-  } else {
-    for (int y = t; y < p.out_h; y += YP_RLE_THREADS) {
-      float f = (float)(((double)y + 0.5) * p.scale_y - 0.5);
-      const int s = (int)floorf(f);
-      s_fy[y] = f - (float)s;
-      s_sy[y] = (short)s;
-    }
-    __syncthreads();
+  // vertical coefficients of every output row (weights kept, row indices clipped at use).  (Keeping them
+  // in registers per lane instead was slower: 16 unrolled chunks spilled at the 128 VGPRs a 1024-thread
+  // workgroup is allowed - 2.6 ms against 1.7 at config 2.)
+  for (int y = t; y < p.out_h; y += YP_RLE_THREADS) {
+    float f = (float)(((double)y + 0.5) * p.scale_y - 0.5);
+    const int s = (int)floorf(f);
+    s_fy[y] = f - (float)s;
+    s_sy[y] = (short)s;
   }
+  __syncthreads();
 
-  const u64 lt_mask = (1ull << lane) - 1ull;
   const int cpw = p.ncols / YP_RLE_WAVES;        // columns per wave and batch
   int total = 0;              // boundaries before the current batch (identical in every thread)
   int last_pos = 0;           // position of the last boundary so far (0: none yet)
@@ -154,7 +137,6 @@ __global__ __launch_bounds__(YP_RLE_THREADS) void mask_rle_kernel(const RleArgs 
       const int col = __builtin_amdgcn_readfirstlane(wave * cpw + q);   // column of the batch, wave-uniform
       if (col >= nc) break;
       const int x = x0 + col;
-      const int col_start = x * p.out_h;
       // ---- A: horizontal pass for this column ------------------------------------------------------
       if (!identity) {
         int sx; float fx; bool right;
@@ -176,104 +158,86 @@ __global__ __launch_bounds__(YP_RLE_THREADS) void mask_rle_kernel(const RleArgs 
         __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0): single wave, LDS in order
         __builtin_amdgcn_wave_barrier();
       }
-      // ---- B: vertical pass, threshold, bits and boundaries --------------------------------------
-      int cnt = 0, carry = 0, lastpos = -1;
-      u64 m0 = 0ull;
+      // ---- B: vertical pass, threshold, 64 bitmap bits per step --------------------------------------
+      // lane c keeps chunk c's bits (two v_cndmask per chunk; nothing scalar but the ballot), and the
+      // column's chunks go to LDS with one store
+      u64 mym = 0ull;
       auto chunk = [&](int c, int r0, int r1, float f) {
-        float w0, w1;
-        if (!fixed) { w0 = one - f; w1 = f; }
-        else { w0 = __int_as_float((int)rintf((one - f) * cscale)); w1 = __int_as_float((int)rintf(f * cscale)); }
         const int y = c * 64 + lane;
         bool bit = false;
         if (y < p.out_h) {
           if (identity) {
             bit = S[(size_t)y * p.pw + x] > p.threshold;
           } else if (!fixed) {
-            const float v = s_hcol[r0] * w0 + s_hcol[r1] * w1;
+            const float v = s_hcol[r0] * (one - f) + s_hcol[r1] * f;
             bit = v > p.threshold;                                                             // coco_eval.py:135
           } else {
-            const int ib0 = __float_as_int(w0), ib1 = __float_as_int(w1);
+            const int ib0 = (int)rintf((one - f) * cscale), ib1 = (int)rintf(f * cscale);
             const int v = (((ib0 * (s_hcol_i[r0] >> 4)) >> 16) + ((ib1 * (s_hcol_i[r1] >> 4)) >> 16) + 2) >> 2;
             bit = (v & 0xff) != 0;
           }
         }
         const u64 m = __ballot(bit);
-        const int nvalid = min(64, p.out_h - c * 64);
-        const u64 vmask = nvalid == 64 ? ~0ull : ((1ull << nvalid) - 1ull);
-        // a boundary wherever a pixel differs from the one before it; the column's first pixel is
-        // compared with the previous COLUMN's last pixel in phase C, so it is excluded here
-        const u64 tr = (m ^ ((m << 1) | (u64)(c == 0 ? (int)(m & 1ull) : carry))) & vmask;
-        carry = (int)((m >> (nvalid - 1)) & 1ull);
-        cnt += __popcll(tr);
-        if (tr != 0ull) lastpos = col_start + c * 64 + (63 - __clzll((long long)tr));
-        if (c == 0) m0 = m;
-        if (lane == 0) { s_bits[col * HB + c] = m; s_trans[col * HB + c] = tr; }
+        mym = lane == c ? m : mym;
       };
-      if (FAST) {
-#pragma unroll
-        for (int c = 0; c < YP_RLE_FAST_HB; ++c)
-          if (c < HB) chunk(c, vr[c] & 0xffff, vr[c] >> 16, vf[c]);
-      } else {
-        for (int c = 0; c < HB; ++c) {
-          const int y = min(c * 64 + lane, p.out_h - 1);
-          const int s = s_sy[y];
-          const float f = s_fy[y];
-          const int r0 = min(max(s, 0), phm1), r1 = min(max(s + 1, 0), phm1);
-          chunk(c, r0, r1, f);
-        }
+      for (int c = 0; c < HB; ++c) {
+        const int y = min(c * 64 + lane, p.out_h - 1);
+        const int s = s_sy[y];
+        const float f = s_fy[y];
+        const int r0 = min(max(s, 0), phm1), r1 = min(max(s + 1, 0), phm1);
+        chunk(c, r0, r1, f);
       }
-      if (lane == 0) {
-        s_first[col] = (int)(m0 & 1ull);
-        s_lastbit[col] = carry;
-        s_count[col] = cnt;
-        s_lastpos[col] = lastpos;
-      }
+      if (lane < HB) s_bits[col * HB + lane] = mym;
       __builtin_amdgcn_s_waitcnt(0xC07F);        // this column's hcol reads are done before the next column rewrites it
       __builtin_amdgcn_wave_barrier();
     }
     __syncthreads();
-    // ---- C: one lane per column: where do the batch's boundaries go? --------------------------------
-    int c_first = 0, c_cnt = 0, c_cand = -1;
+    // ---- C: one thread per (column, 64-row chunk) cell: boundaries, their places, the run lengths ----
     {
-      const bool have = lane < nc;
-      const int cl = have ? lane : 0;
-      const int fb = s_first[cl], pb = lane == 0 ? prev_lastbit : s_lastbit[max(cl - 1, 0)];
-      c_first = have && (fb != pb) ? 1 : 0;                              // the column's first pixel starts a run
-      c_cnt = have ? s_count[cl] : 0;
-      const int lpz = s_lastpos[cl];
-      c_cand = !have ? -1 : (lpz >= 0 ? lpz : (c_first ? (x0 + cl) * p.out_h : -1));   // last boundary inside column cl
-    }
-    const int tot = c_first + c_cnt;
-    const int incl = wave_incl_add(tot, lane);
-    const int excl = incl - tot;                                         // boundaries of the batch before column `lane`
-    const int inclmax = wave_incl_max(c_cand, lane);
-    int exclmax = __shfl_up(inclmax, 1);
-    if (lane == 0) exclmax = -1;
-    const int lp_before = max(last_pos, exclmax);                        // last boundary before column `lane`
-    for (int q = 0; q < cpw; ++q) {
-      const int col = __builtin_amdgcn_readfirstlane(wave * cpw + q);
-      if (col >= nc) break;
-      const int col_start = (x0 + col) * p.out_h;
-      int off = total + __builtin_amdgcn_readlane(excl, col);
-      int lp = __builtin_amdgcn_readlane(lp_before, col);
-      if (__builtin_amdgcn_readlane(c_first, col)) {
-        if (lane == 0 && off < p.cap) counts[off] = (uint32_t)(col_start - lp);
-        off += 1;
-        lp = col_start;
+      const int ncell = nc * HB;
+      const bool have = t < ncell;
+      const int ccol = have ? t / HB : 0, cc = have ? t - ccol * HB : 0;
+      const int cell_start = (x0 + ccol) * p.out_h + cc * 64;
+      const u64 m = have ? s_bits[t] : 0ull;
+      const u64 pm = s_bits[max(min(t, ncell) - 1, 0)];            // the cell before this one in column-major order
+      const int nvalid = min(64, p.out_h - cc * 64);
+      const u64 vmask = nvalid == 64 ? ~0ull : ((1ull << nvalid) - 1ull);
+      const int nv_last = p.out_h - (HB - 1) * 64;                  // valid rows of a column's last chunk
+      // a boundary wherever a pixel differs from the one before it (column-major); the first pixel of a
+      // column is compared with the last pixel of the previous column, the very first one with 0
+      int before;
+      if (cc > 0) before = (int)(pm >> 63);
+      else if (t == 0) before = prev_lastbit;
+      else before = (int)((pm >> (nv_last - 1)) & 1ull);
+      u64 tr = have ? (m ^ ((m << 1) | (u64)before)) & vmask : 0ull;
+      const int tot = __popcll(tr);
+      const int cand = tr != 0ull ? cell_start + (63 - __clzll((long long)tr)) : -1;   // last boundary inside the cell
+      // workgroup-wide exclusive sum of tot and exclusive max of cand, in cell order
+      const int incl = wave_incl_add(tot, lane);
+      const int inclmax = wave_incl_max(cand, lane);
+      if (lane == 63) { s_wsum[wave] = incl; s_wmax[wave] = inclmax; }
+      __syncthreads();
+      int base = 0, basemax = -1, btot = 0, bmax = -1;
+#pragma unroll
+      for (int w = 0; w < YP_RLE_WAVES; ++w) {
+        const int ws_ = s_wsum[w], wm_ = s_wmax[w];
+        if (w < wave) { base += ws_; basemax = max(basemax, wm_); }
+        btot += ws_; bmax = max(bmax, wm_);
       }
-      for (int c = 0; c < HB; ++c) {
-        const u64 tr = s_trans[col * HB + c];
-        if (tr == 0ull) continue;                // wave-uniform
-        if ((tr >> lane) & 1ull) {
-          const u64 below = tr & lt_mask;
-          const int pos = col_start + c * 64 + lane;
-          const int prev = below ? col_start + c * 64 + (63 - __clzll((long long)below)) : lp;
-          const int j = off + __popcll(below);
-          if (j < p.cap) counts[j] = (uint32_t)(pos - prev);
-        }
-        off += __popcll(tr);
-        lp = col_start + c * 64 + (63 - __clzll((long long)tr));
+      int exclmax = __shfl_up(inclmax, 1);
+      if (lane == 0) exclmax = -1;
+      int j = total + base + incl - tot;
+      int lp = max(last_pos, max(basemax, exclmax));
+      while (tr != 0ull) {                                           // count j = boundary j minus boundary j-1
+        const int pos = cell_start + __builtin_ctzll(tr);
+        tr &= tr - 1ull;
+        if (j < p.cap) counts[j] = (uint32_t)(pos - lp);
+        ++j;
+        lp = pos;
       }
+      total += btot;
+      last_pos = max(last_pos, bmax);
+      prev_lastbit = (int)((s_bits[ncell - 1] >> (nv_last - 1)) & 1ull);
     }
     // ---- the row-major bitmap: nc bytes of every row per batch (train.py:502-506's detection_masks) ----
     if (bitmap) {
@@ -282,9 +246,6 @@ __global__ __launch_bounds__(YP_RLE_THREADS) void mask_rle_kernel(const RleArgs 
         if (xc < nc) bitmap[(size_t)y * p.out_w + x0 + xc] = (uint8_t)((s_bits[xc * HB + (y >> 6)] >> (y & 63)) & 1ull);
       }
     }
-    total += __builtin_amdgcn_readlane(incl, 63);
-    last_pos = max(last_pos, __builtin_amdgcn_readlane(inclmax, 63));
-    prev_lastbit = s_lastbit[nc - 1];
     __syncthreads();                             // LDS is rewritten by the next batch
   }
   if (t == 0) {
@@ -311,17 +272,14 @@ hipError_t yp_launch_mask_rle(int batch, int max_dets, int ph, int pw, const flo
   while (nc > 16 && (long long)ph * width(nc) > YP_RLE_SRC_FLOATS) nc -= 16;
   a.ncols = nc;
   a.ws = (long long)ph * width(nc) <= YP_RLE_SRC_FLOATS ? (width(nc) < pw ? width(nc) : pw) : 0;
-  const bool fast = HB <= YP_RLE_FAST_HB;
   static bool attr_set = false;
   if (!attr_set) {   // up to ~113 KiB of dynamic LDS at the largest supported sizes
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mask_rle_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mask_rle_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mask_rle_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  size_t lds = (size_t)((ph * a.ws * 4 + 15) & ~15) + (size_t)((YP_RLE_WAVES * ph * 4 + 15) & ~15) + 2 * YP_RLE_CELLS * 8 +
-               4 * YP_RLE_MAX_COLS * 4 + (fast ? 0 : (size_t)out_h * 6 + 16);
-  if (fast) hipLaunchKernelGGL((mask_rle_kernel<true>), dim3(max_dets, batch), dim3(YP_RLE_THREADS), lds, st, a);
-  else hipLaunchKernelGGL((mask_rle_kernel<false>), dim3(max_dets, batch), dim3(YP_RLE_THREADS), lds, st, a);
+  const size_t lds = (size_t)((ph * a.ws * 4 + 15) & ~15) + (size_t)((YP_RLE_WAVES * ph * 4 + 15) & ~15) + YP_RLE_CELLS * 8 +
+                     2 * YP_RLE_WAVES * 4 + (size_t)out_h * 6 + 16;
+  hipLaunchKernelGGL(mask_rle_kernel, dim3(max_dets, batch), dim3(YP_RLE_THREADS), lds, st, a);
   return hipGetLastError();
 }
 
