@@ -187,6 +187,7 @@ extern "C" int yp_create(const yp_config* cfg, yp_handle** out) {
   (void)hipDeviceSynchronize();
 #ifdef YP_STAMPS
   (void)hipMalloc(&h->dbg, 3 * 4096 * 16 * 8); (void)hipMemset(h->dbg, 0, 3 * 4096 * 16 * 8);
+  (void)hipMemset((char*)h->dbg + (size_t)2 * 4096 * 16 * 8, 0xff, 8);   // fill start: running minimum
 #endif
   *out = h;
   g_err[0] = 0;

@@ -71,7 +71,7 @@ struct NmsArgs {
 };
 #ifdef YP_STAMPS
 #define STAMP_INIT(kern, blk) unsigned long long* const dbg_ = p.dbg + ((size_t)(kern) * 4096 + (blk)) * 16; if (threadIdx.x == 0) dbg_[15] = 1
-#define STAMP(i) do { if (threadIdx.x == 0) dbg_[i] = (unsigned long long)clock64(); } while (0)
+#define STAMP(i) do { if (threadIdx.x == 0) dbg_[i] = (unsigned long long)wall_clock64(); } while (0)   /* 100 MHz, comparable across workgroups */
 #else
 #define STAMP_INIT(kern, blk)
 #define STAMP(i)
@@ -151,20 +151,40 @@ struct PartSrc {   // score_filter's lists of one image: nparts lists of `cap` s
     }
   }
 };
+#define YP_POOL_PRE 8   // keys per thread of PoolSrc's first batch, loaded before the list lengths are known
 struct PoolSrc {   // ngroups lists of gcap slots; list g holds its keys at [0, start[g+1] - start[g])
   const u64* base;
   const int* start;   // LDS: exclusive prefix of the list lengths, ngroups + 1 entries
   int ngroups, gcap;
+  const u64* pre;     // this thread's first YP_POOL_PRE keys (registers), loaded by preload()
+  __device__ __forceinline__ int shift() const {
+    int sft = 0;      // 1 << sft threads share a list
+    while ((2 << sft) * ngroups <= (int)blockDim.x && sft < 6) ++sft;
+    return sft;
+  }
+  // The first batch of every list, issued WITHOUT waiting for the lengths (slots past a list's end hold
+  // stale keys, still inside its allocation), so that lengths and keys share one round trip.  Needs
+  // ngroups << shift() <= blockDim.x (16 groups: always).
+  __device__ __forceinline__ void preload(u64* k) const {
+    const int sft = shift(), lpp = 1 << sft;
+    const int s = min((int)threadIdx.x, (ngroups << sft) - 1);
+    const int g = s >> sft, q = s & (lpp - 1);
+    const u64* l = base + (size_t)g * gcap;
+#pragma unroll
+    for (int u = 0; u < YP_POOL_PRE; ++u) k[u] = l[min(q + u * lpp, gcap - 1)];
+  }
   template <int THREADS, class F>
   __device__ __forceinline__ void for_each(F f) const {
-    int sft = 0;     // 1 << sft threads share a list
-    while ((2 << sft) * ngroups <= THREADS && sft < 6) ++sft;
-    const int lpp = 1 << sft;
-    for (int s = threadIdx.x; s < (ngroups << sft); s += THREADS) {
+    const int sft = shift(), lpp = 1 << sft;
+    const int s = threadIdx.x;
+    if (s < (ngroups << sft)) {
       const int g = s >> sft, q = s & (lpp - 1);
       const int n = start[g + 1] - start[g];
       const u64* l = base + (size_t)g * gcap;
-      for (int i0 = q; i0 < n; i0 += lpp * YP_SRC_UNROLL) {
+#pragma unroll
+      for (int u = 0; u < YP_POOL_PRE; ++u)
+        if (q + u * lpp < n) f(pre[u]);
+      for (int i0 = q + lpp * YP_POOL_PRE; i0 < n; i0 += lpp * YP_SRC_UNROLL) {
         u64 k[YP_SRC_UNROLL];
 #pragma unroll
         for (int u = 0; u < YP_SRC_UNROLL; ++u) k[u] = l[min(i0 + u * lpp, n - 1)];
@@ -334,7 +354,7 @@ template <int THREADS, class Src>
 __device__ __forceinline__ int select_topk_sorted(const Src& src, int n, int want, SelectShared& sh, u64* stage, int stage_cap,
                                                   unsigned long long* dbg_ = nullptr) {
 #ifdef YP_STAMPS
-#define SSTAMP(i) do { if (dbg_ && threadIdx.x == 0) dbg_[i] = (unsigned long long)clock64(); } while (0)
+#define SSTAMP(i) do { if (dbg_ && threadIdx.x == 0) dbg_[i] = (unsigned long long)wall_clock64(); } while (0)
 #else
 #define SSTAMP(i)
 #endif
@@ -568,6 +588,10 @@ __host__ __device__ inline long long fill_chunks_per_image(long long P, int rows
 }
 template <int THREADS>
 __device__ __forceinline__ void fill_block(const NmsArgs& p, long long ch) {
+#ifdef YP_STAMPS
+  if (threadIdx.x == 0) atomicMin(p.dbg + (size_t)2 * 4096 * 16 + 0, (unsigned long long)wall_clock64());
+  struct AtEnd { const NmsArgs& p; __device__ ~AtEnd() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); if (threadIdx.x == 0) atomicMax(p.dbg + (size_t)2 * 4096 * 16 + 1, (unsigned long long)wall_clock64()); } } at_end{p};
+#endif
   const long long cpi4 = fill_chunks_per_image<THREADS>(p.fill_P, p.fill_rows, 4);
   const long long n4 = p.fill_masks ? cpi4 * p.batch : 0;
   if (ch < n4) {
@@ -853,19 +877,25 @@ __device__ __forceinline__ void final_select_body(const NmsArgs& p, int b, Group
   const int t = threadIdx.x;
   STAMP_INIT(1, b);
   STAMP(0);
-  if (t == 0) {
-    int acc = 0;
-    for (int g = 0; g < p.ngroups; ++g) { start[g] = acc; acc += p.pool_count[(size_t)b * p.ngroups + g]; }
-    start[p.ngroups] = acc;
-  }
+  // one round trip: the groups' list lengths, the first batch of their keys, the survivor counts
+  PoolSrc src{p.pool + (size_t)b * p.ngroups * p.gcap, start, p.ngroups, p.gcap, nullptr};
+  u64 pre[YP_POOL_PRE];
+  src.preload(pre);
+  src.pre = pre;
+  int cnt = 0;
+  if (t < p.ngroups) cnt = p.pool_count[(size_t)b * p.ngroups + t];
   int part = 0;
   for (int i = t; i < p.parts; i += THREADS) part += p.seg_surv[(size_t)b * p.parts + i];
+  if (t < 64) {                                   // ngroups <= 16: exclusive prefix of the lengths in the first wave
+    const int incl = wave_incl_scan(cnt);
+    if (t < p.ngroups) start[t + 1] = incl;
+    if (t == 0) start[0] = 0;
+  }
   const int survivors = block_sum<THREADS>(part, sh.wtot);   // (its barriers also publish start[])
   const int n = start[p.ngroups];
   STAMP(1);
   int k = 0;
   if (n > 0) {
-    const PoolSrc src{p.pool + (size_t)b * p.ngroups * p.gcap, start, p.ngroups, p.gcap};
 #ifdef YP_STAMPS
     k = select_topk_sorted<THREADS>(src, n, min(p.max_dets, YP_SORT_MAX), sh, gs.stage, YP_GSTAGE_CAP, dbg_);
 #else
