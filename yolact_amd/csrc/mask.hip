@@ -43,7 +43,7 @@ struct MaskArgs {
 // Workgroups of one image are placed on one XCD (the dispatcher deals consecutive workgroup ids
 // round-robin over the 8 XCDs), so the partial cache lines at workgroup borders (mask rows are
 // only 16-byte aligned: P*4 bytes is not a multiple of 128) merge in a single L2.
-template <bool NT_STORE>
+template <bool NT_STORE, int NG>   // NG: 64-detection groups the kernel looks at (sel_rows <= 64 * NG)
 __global__ __launch_bounds__(YP_MASK_BLOCK) void mask_assemble_kernel(const MaskArgs p, int blocks_per_image, int batch, int by_xcd) {
   __shared__ float4 sproto[YP_MASK_BLOCK * YP_MASK_ROW4];
   typedef float nat4 __attribute__((ext_vector_type(4)));
@@ -76,14 +76,16 @@ __global__ __launch_bounds__(YP_MASK_BLOCK) void mask_assemble_kernel(const Mask
   // the compiler cannot prove it), so that walking the bits is scalar work.
   const int lane = t & 63;
   const int w0 = base_pix + __builtin_amdgcn_readfirstlane(t >> 6) * 64, w1 = min(w0 + 63, p.P - 1);
-  u64 rel[YP_SORT_MAX / 64] = {0ull, 0ull, 0ull, 0ull};
+  u64 rel[NG];
+#pragma unroll
+  for (int g = 0; g < NG; ++g) rel[g] = 0ull;
   if (w0 < p.P) {
     const int r0 = w0 / p.pw, r1 = w1 / p.pw;
     int c0 = w0 - r0 * p.pw, c1 = w1 - r1 * p.pw;
     if (r1 > r0) { c0 = 0; c1 = p.pw - 1; }
     const float fr0 = (float)r0, fr1 = (float)r1, fc0 = (float)c0, fc1 = (float)c1;
 #pragma unroll
-    for (int g = 0; g < YP_SORT_MAX / 64; ++g) {
+    for (int g = 0; g < NG; ++g) {
       if (g * 64 < N) {
         const int n = g * 64 + lane;
         const float4 cb = p.crop[(size_t)b * p.sel_rows + min(n, N - 1)];
@@ -96,7 +98,10 @@ __global__ __launch_bounds__(YP_MASK_BLOCK) void mask_assemble_kernel(const Mask
   }
   // Rows already zero-filled: a workgroup none of whose waves is touched by any detection has
   // nothing to write.
-  if (p.prezeroed && __syncthreads_or((rel[0] | rel[1] | rel[2] | rel[3]) != 0ull) == 0) return;
+  u64 any_rel = 0ull;
+#pragma unroll
+  for (int g = 0; g < NG; ++g) any_rel |= rel[g];
+  if (p.prezeroed && __syncthreads_or(any_rel != 0ull) == 0) return;
 
   float pr[YP_MASK_DIM];
   {
@@ -172,7 +177,7 @@ __global__ __launch_bounds__(YP_MASK_BLOCK) void mask_assemble_kernel(const Mask
   // per-wave zero pass: this wave rewrites its own addresses below; its zeros are acknowledged first
   if (!p.prezeroed && !wide) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-  for (int g = 0; g < YP_SORT_MAX / 64; ++g) {
+  for (int g = 0; g < NG; ++g) {
     u64 w = g * 64 < N ? rel[g] : 0ull;        // wave-uniform
     while (w != 0ull) {
       const int n = g * 64 + __builtin_ctzll(w);
@@ -248,8 +253,10 @@ hipError_t yp_launch_mask_assemble(const yp_handle* h, int batch, const float* p
   const dim3 grid(by_xcd ? 8 * ((batch + 7) / 8) * bpi : batch * bpi);
   // Default-policy stores: the zeros the fill has just written usually still sit (dirty) in the
   // Infinity Cache, and these stores overwrite them there.  (tune.mask_nt: non-temporal instead.)
-  if (h->tune.mask_nt) hipLaunchKernelGGL((mask_assemble_kernel<true>), grid, dim3(YP_MASK_BLOCK), 0, st, a, bpi, batch, by_xcd);
-  else hipLaunchKernelGGL((mask_assemble_kernel<false>), grid, dim3(YP_MASK_BLOCK), 0, st, a, bpi, batch, by_xcd);
+  const int ng = (a.sel_rows + 63) / 64;
+#define YP_MASK_LAUNCH(NT, NG) hipLaunchKernelGGL((mask_assemble_kernel<NT, NG>), grid, dim3(YP_MASK_BLOCK), 0, st, a, bpi, batch, by_xcd)
+  if (h->tune.mask_nt) { if (ng <= 1) YP_MASK_LAUNCH(true, 1); else if (ng <= 2) YP_MASK_LAUNCH(true, 2); else YP_MASK_LAUNCH(true, 4); }
+  else { if (ng <= 1) YP_MASK_LAUNCH(false, 1); else if (ng <= 2) YP_MASK_LAUNCH(false, 2); else YP_MASK_LAUNCH(false, 4); }
   return hipGetLastError();
 }
 
@@ -287,6 +294,6 @@ hipError_t yp_launch_loss_masks(int batch, int rows, int ph, int pw, int img_h, 
   const int bpi = (a.P + YP_MASK_BLOCK - 1) / YP_MASK_BLOCK;
   const int by_xcd = batch >= 8 ? 1 : 0;
   const dim3 grid(by_xcd ? 8 * ((batch + 7) / 8) * bpi : batch * bpi);
-  hipLaunchKernelGGL((mask_assemble_kernel<false>), grid, dim3(YP_MASK_BLOCK), 0, st, a, bpi, batch, by_xcd);
+  hipLaunchKernelGGL((mask_assemble_kernel<false, 4>), grid, dim3(YP_MASK_BLOCK), 0, st, a, bpi, batch, by_xcd);
   return hipGetLastError();
 }
