@@ -457,3 +457,70 @@ def test_current_device_is_left_alone(torch_cuda):
     sd = ShardedDetect(5, 300, 100, 0.05, 0.5, devices=[0, 0])
     sd(net, shp)
     assert torch.cuda.current_device() == before
+
+
+def test_yp_run_under_hip_graph_capture(torch_cuda):
+    """yp_run allocates nothing, creates nothing and never synchronises, so a caller can capture it in a
+    HIP graph (serving loops): captured once, replayed on new inputs written into the same buffers, the
+    outputs are bit-identical to eager calls.  The allocation-free entry point is captured the same way
+    (after one eager call, which resolves the static scratch's address)."""
+    import ctypes
+    torch = torch_cuda
+    from yolact_amd import _lib, PostConfig, PostProcessor, synth
+    netA, shp = synth.make_toy(51, batch=4)
+    netB, _ = synth.make_toy(52, batch=4)
+    B, A, C = netA["pred_cls"].shape
+    for mode in ("cc", "per_class"):
+        pc = PostConfig(A, C, 12, 12, 64, 64, nms_mode=mode, top_k=40, max_dets=20, max_batch=B)
+        pp = PostProcessor(pc)
+        keys = ("pred_offset", "pred_cls", "pred_mask_coef", "priors", "proto_out")
+        buf = {k: torch.from_numpy(netA[k]).cuda() for k in keys}
+        eager = {}
+        for name, net in (("A", netA), ("B", netB)):
+            for k in keys:
+                buf[k].copy_(torch.from_numpy(net[k]))
+            eager[name] = {k: v.clone() for k, v in pp.run(*[buf[k] for k in keys]).items()}
+        torch.cuda.synchronize()
+        out = pp.alloc_outputs(B)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            pp.run(*[buf[k] for k in keys], out=out)
+        for name, net in (("B", netB), ("A", netA), ("B", netB)):
+            for k in keys:
+                buf[k].copy_(torch.from_numpy(net[k]))
+            g.replay()
+            torch.cuda.synchronize()
+            n = eager[name]["num_detections"].cpu().numpy()
+            for k in ("detection_boxes", "detection_classes", "detection_scores", "detection_anchor_indices", "num_detections"):
+                assert torch.equal(out[k], eager[name][k]), (mode, name, k)
+            for b in range(B):
+                assert torch.equal(out["detection_masks"][b, :n[b]], eager[name]["detection_masks"][b, :n[b]]), (mode, name, b)
+        # the allocation-free entry point under capture
+        L = _lib.load()
+        c = _lib.YpConfig(num_anchors=A, num_classes=C, mask_dim=32, proto_h=12, proto_w=12, img_h=64, img_w=64, conf_thresh=0.05,
+                          nms_thresh=0.5, nms_mode={"cc": 0, "per_class": 1}[mode], top_k=40, max_dets=20, use_cropped_mask=1,
+                          zero_pad_masks=0, mask_threshold=-1.0, max_batch=1, device_id=0)
+        ptr = lambda t: ctypes.c_void_p(t.data_ptr())
+
+        def call_static():
+            rc = L.yp_run_static(ctypes.byref(c), B, *[ptr(buf[k]) for k in keys], ptr(out["detection_boxes"]),
+                                 ptr(out["detection_classes"]), ptr(out["detection_scores"]), ptr(out["detection_masks"]), None,
+                                 ptr(out["num_detections"]), ptr(out["detection_anchor_indices"]),
+                                 ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+            assert rc == 0, L.yp_last_error()
+
+        call_static()                       # resolves the scratch address, plans the configuration
+        torch.cuda.synchronize()
+        g2 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g2):
+            call_static()
+        for name, net in (("A", netA), ("B", netB)):
+            for k in keys:
+                buf[k].copy_(torch.from_numpy(net[k]))
+            for v in out.values():
+                v.zero_()
+            g2.replay()
+            torch.cuda.synchronize()
+            for k in ("detection_boxes", "detection_scores", "detection_anchor_indices", "num_detections"):
+                assert torch.equal(out[k], eager[name][k]), (mode, name, k, "static")
+        pp.close()
