@@ -246,6 +246,27 @@ def test_per_class_large_groups_and_classes(torch_cuda):
     check_vs_c_oracle(torch_cuda, net, shp, mode="cc", top_k=256, max_dets=300, label="large-groups-cc")
 
 
+def test_per_class_groups_beyond_the_lds_key_array(torch_cuda):
+    """~3400 candidates in each of two classes: more than the 1536 keys a class group keeps in LDS, so its
+    class-by-class path reads the image's lists again for every class; its pooled survivors (> max_dets)
+    are cut to the group's best max_dets before the image's selection."""
+    from yolact_amd import synth
+    net, shp = synth.make_toy(24, batch=2, fmaps=((48, 48), (8, 8)), num_classes=3, p_fg=0.97)   # A = 7104
+    got, ref = check_vs_c_oracle(torch_cuda, net, shp, mode="per_class", top_k=200, max_dets=100, label="huge-groups")
+    assert (ref["num_survivors"] > 6000).all()
+
+
+@pytest.mark.parametrize("max_dets", [5, 20, 100])
+def test_per_class_group_pool_cut_to_max_dets(torch_cuda, max_dets):
+    """A class group of the thread-per-candidate path (a few hundred candidates) whose NMS survivors
+    outnumber max_dets: the group hands only its best max_dets to the image's selection, which must not
+    change the result (top max_dets of the union = top max_dets of the groups' top max_dets)."""
+    from yolact_amd import synth
+    net, shp = synth.make_toy(25, batch=3, fmaps=((16, 16), (4, 4)), num_classes=4, p_fg=0.8)   # A = 816
+    got, ref = check_vs_c_oracle(torch_cuda, net, shp, mode="per_class", top_k=200, max_dets=max_dets, label=f"pool-cut-{max_dets}")
+    assert (ref["num_detections"] == max_dets).all()
+
+
 def test_more_work_items_than_resident_waves(torch_cuda):
     """4000 small images: score_filter has more work items than resident waves and walks them
     grid-stride; every NMS workgroup finds one list per image."""

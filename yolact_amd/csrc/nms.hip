@@ -33,6 +33,7 @@
                              // beside 2 NMS workgroups)
 #define YP_GROUP_CAP 1024    // thread slots for the candidates of one class group (threads x YP_GROUP_KPT)
 #define YP_GROUP_LDS 768     // candidates of one class group that the thread-per-candidate path holds in LDS
+#define YP_GROUP_KEYS (2 * YP_GROUP_LDS)   // keys of a larger group that still stay in LDS for its class-by-class path
 #define YP_GROUP_THREADS 512
 #define YP_GROUP_KPT (YP_GROUP_CAP / YP_GROUP_THREADS)
 
@@ -117,15 +118,21 @@ struct PartSrc {   // score_filter's lists of one image: nparts lists of `cap` s
   long long cap;
   int cls;           // > 0: only the keys of this class
   int gmod, grem;    // gmod > 0: only the keys of classes c with (c - 1) % gmod == grem
-  __device__ __forceinline__ bool take(u64 k) const {
+  // (c - 1) % gmod without the integer division: for 0 <= x < 256 and gmod <= 256, (x + 0.5) / gmod is at
+  // least 0.5 / gmod away from an integer, far more than the float error, so the truncation is x / gmod
+  __device__ __forceinline__ bool take(u64 k, float ginv) const {
     const int c = yp_seg_key_class(k);
-    return (cls == 0 || c == cls) && (gmod == 0 || (c - 1) % gmod == grem);
+    if (cls != 0 && c != cls) return false;
+    if (gmod == 0) return true;
+    const int q = (int)(((float)(c - 1) + 0.5f) * ginv);
+    return (c - 1) - q * gmod == grem;
   }
   template <int THREADS, class F>
   __device__ __forceinline__ void for_each(F f) const {
     int sft = 0;     // 1 << sft threads share a list: as many as the workgroup has to spare
     while ((2 << sft) * nparts <= THREADS && sft < 6) ++sft;
     const int lpp = 1 << sft;
+    const float ginv = 1.0f / (float)max(gmod, 1);
     for (int s = threadIdx.x; s < (nparts << sft); s += THREADS) {
       const int j = s >> sft, q = s & (lpp - 1);
       const int n = counts[j];
@@ -138,7 +145,7 @@ struct PartSrc {   // score_filter's lists of one image: nparts lists of `cap` s
         for (int u = 0; u < YP_PART_UNROLL; ++u) k[u] = l[min((long long)(q + u * lpp), cap - 1)];
 #pragma unroll
         for (int u = 0; u < YP_PART_UNROLL; ++u)
-          if (q + u * lpp < n && take(k[u])) f(k[u]);
+          if (q + u * lpp < n && take(k[u], ginv)) f(k[u]);
       }
       for (int i0 = q + lpp * YP_PART_UNROLL; i0 < n; i0 += lpp * YP_PART_UNROLL) {
         u64 k[YP_PART_UNROLL];
@@ -146,7 +153,7 @@ struct PartSrc {   // score_filter's lists of one image: nparts lists of `cap` s
         for (int u = 0; u < YP_PART_UNROLL; ++u) k[u] = l[min(i0 + u * lpp, n - 1)];
 #pragma unroll
         for (int u = 0; u < YP_PART_UNROLL; ++u)
-          if (i0 + u * lpp < n && take(k[u])) f(k[u]);
+          if (i0 + u * lpp < n && take(k[u], ginv)) f(k[u]);
       }
     }
   }
@@ -452,20 +459,38 @@ __device__ __forceinline__ bool yp_iou_gt(const float4 a, const float4 b, float 
   return (inter == 0.0f ? 0.0f : inter / uni) > thr;
 }
 
-// The n*(n-1)/2 unordered pairs of n items as a rectangle of n rows and n/2 columns: entry (r, c)
-// pairs r with (r + 1 + c) mod n.  Every pair appears once; for even n the last column is the
-// pairs at distance n/2, valid for r < n/2 only.  tri_count() entries in all; tri_pair() returns
-// false for the invalid ones.  (x + 0.5) / w in float is exact here: x < 2^15, w <= 128.)
-__device__ __forceinline__ int tri_count(int n) { return n * (n >> 1); }
-__device__ __forceinline__ bool tri_pair(int x, int n, int& i, int& j) {
-  const int w = n >> 1;
-  const int r = (int)(((float)x + 0.5f) * (1.0f / (float)w));
-  const int c = x - r * w;
-  int q = r + 1 + c;
-  q = q >= n ? q - n : q;
-  i = min(r, q);
-  j = max(r, q);
-  return (n & 1) || c < w - 1 || r < w;
+// Fast NMS pair sweep: sup[j] = 1 for every j < k that some i < j overlaps by more than thr
+// (detection.py:190-202; box i outranks box j).  Column j has j rows; columns f and k-1-f are folded
+// into one of k-1 rows, and the rows of a folded column are cut into G parts, so that ~nf*G threads
+// have equal work.  A thread keeps its two column boxes in registers and reads ONE row box per test;
+// the lanes of a wave share the part, so in the first column's rows they read the same box (an LDS
+// broadcast) and in the second's consecutive ones.  ~25 VALU operations per pair: the sweep is what
+// bounds a saturated image (80 classes x 200 boxes: 1.6 M pairs).
+template <int THREADS, class T>
+__device__ __forceinline__ void pair_sweep(const float4* box, T* sup, int k, float thr) {
+  if (k < 2) return;
+  const int nf = (k + 1) >> 1;
+  const int G = max(1, THREADS / nf);
+  const int L = (k - 1 + G - 1) / G;
+  for (int s = threadIdx.x; s < nf * G; s += THREADS) {   // (one trip unless nf > THREADS)
+    const int part = s / nf, f = s - part * nf;
+    const int jb = k - 1 - f;
+    const int rows = f + (jb != f ? jb : 0);               // (odd k: the middle column is folded with nothing)
+    const int v0 = part * L, v1 = min(v0 + L, rows);
+    if (v0 >= v1) continue;
+    const float4 ba = box[f], bb = box[jb];
+    bool ha = false, hb = false;
+    for (int v = v0; v < v1; ++v) {
+      const bool first = v < f;
+      const float4 bi = box[first ? v : v - f];
+      const float4 bj = first ? ba : bb;
+      const bool hit = yp_iou_gt(bi, bj, thr);
+      ha |= hit && first;
+      hb |= hit && !first;
+    }
+    if (ha) sup[f] = 1;
+    if (hb) sup[jb] = 1;
+  }
 }
 
 // Output row r of image b: sanitize + normalise (detection.py:92-98), class/score/index
@@ -527,12 +552,7 @@ __device__ __forceinline__ void finish_image(const NmsArgs& p, int b, int n, int
 template <int THREADS>
 __device__ __forceinline__ bool fast_nms_keep(const float4* sbox, int* ssup, int* s_wave_cnt, int k, float thr, int& pos, int& total) {
   const int t = threadIdx.x;
-  // the k*(k-1)/2 pairs are dealt evenly to the threads: independent iterations, no long column
-  const int npairs = tri_count(k);
-  for (int x = t; x < npairs; x += THREADS) {
-    int i, j;
-    if (tri_pair(x, k, i, j) && yp_iou_gt(sbox[i], sbox[j], thr)) ssup[j] = 1;
-  }
+  pair_sweep<THREADS>(sbox, ssup, k, thr);
   __syncthreads();
   bool keep = false;
   if (t < k) keep = ssup[t] == 0;
@@ -714,12 +734,29 @@ static_assert(YP_GSTAGE_CAP * sizeof(u64) >= 2 * YP_GROUP_LDS * sizeof(u64) + YP
 // Top_k + Fast NMS of ONE class with the whole workgroup (any number of candidates): the path for
 // groups too large for the thread-per-candidate code.  Appends the survivors to pool[base...] and
 // returns their number.  All threads must call it.
-template <int THREADS>
-__device__ __forceinline__ int class_nms_blockwide(const NmsArgs& p, int b, int cls, GroupShared& gs, u64* pool, int base) {
+struct LdsClassSrc {   // the keys of one class among n keys that sit in LDS
+  const u64* keys;
+  int n, cls;
+  template <int THREADS, class F>
+  __device__ __forceinline__ void for_each(F f) const {
+    for (int i = threadIdx.x; i < n; i += THREADS) {
+      const u64 k = keys[i];
+      if (yp_seg_key_class(k) == cls) f(k);
+    }
+  }
+};
+
+template <int THREADS, class SRC>
+__device__ __forceinline__ int class_nms_blockwide(const NmsArgs& p, int b, int cls, const SRC& src, GroupShared& gs, u64* pool, int base) {
   const int t = threadIdx.x;
   SelectShared& sh = gs.sh;
   float4* sbox = gs.box;
-  const PartSrc src{p.cand + (size_t)b * p.parts * p.cap_item, p.seg_count + (size_t)b * p.parts, p.parts, p.cap_item, cls, 0, 0};
+#ifdef YP_STAMPS   // stamps 2..6 of the group's row: its FIRST class
+  unsigned long long* const dbg_ = p.dbg + (size_t)(b * p.ngroups + (cls - 1) % p.ngroups) * 16;
+#define CSTAMP(i) do { if (cls <= p.ngroups) STAMP(i); } while (0)
+#else
+#define CSTAMP(i)
+#endif
   __syncthreads();
   if (t == 0) sh.fill = 0;
   if (t < YP_SORT_MAX) { gs.ssup[t] = 0; sh.rank[t] = 0; }
@@ -731,6 +768,7 @@ __device__ __forceinline__ int class_nms_blockwide(const NmsArgs& p, int b, int 
   __syncthreads();
   const int n = sh.fill;
   if (n == 0) return 0;
+  CSTAMP(2);
   int k;
   if (n <= YP_SORT_MAX) {
     rank_sort_desc<THREADS>(sh, n);
@@ -739,17 +777,21 @@ __device__ __forceinline__ int class_nms_blockwide(const NmsArgs& p, int b, int 
     __syncthreads();   // everybody has read sh.fill
     k = select_topk_sorted<THREADS>(src, n, p.top_k, sh, nullptr, 0);             // detection.py:217
   }
+  CSTAMP(3);
   if (t < k) {                                                                          // detection.py:219
     const int a = min(yp_seg_key_anchor(sh.key[t]), p.A - 1);   // (clamp: never index out of bounds)
     sbox[t] = yp_decode(p.priors[a], p.off[(size_t)b * p.A + a]);
   }
   __syncthreads();
+  CSTAMP(4);
   int pos, total;
   const bool keep = fast_nms_keep<THREADS>(sbox, gs.ssup, gs.s_wave_cnt, k, p.nms_thresh, pos, total);
+  CSTAMP(5);
   if (keep) {                                                                           // detection.py:234-239
     const u64 key = sh.key[t];
     store_wt(&pool[base + pos], yp_fin_key(yp_key_score(key), yp_seg_key_anchor(key), cls));
   }
+  CSTAMP(6);
   return total;
 }
 
@@ -769,7 +811,7 @@ __device__ __forceinline__ void group_nms_body(const NmsArgs& p, int b, int g, G
   const PartSrc src{p.cand + (size_t)b * p.parts * p.cap_item, p.seg_count + (size_t)b * p.parts, p.parts, p.cap_item, 0, p.ngroups, g};
   src.template for_each<THREADS>([&](u64 key) {
     const int q = lds_append_slot(&gs.fill);
-    if (q < YP_GROUP_LDS) gs.a[q] = key;
+    if (q < YP_GROUP_KEYS) gs.a[q] = key;   // (a and bk are one array of YP_GROUP_KEYS keys here)
     atomicAdd(&gs.cls_cnt[yp_seg_key_class(key)], 1);
   });
   __syncthreads();
@@ -780,10 +822,33 @@ __device__ __forceinline__ void group_nms_body(const NmsArgs& p, int b, int g, G
     return;
   }
   if (m > YP_GROUP_LDS) {
-    // too many for LDS: class by class, each with the whole workgroup
+    // too many for a thread per candidate: class by class, each with the whole workgroup; from the keys in
+    // LDS while they fit (a | bk as one array; the sorted boxes and a select's histogram lie behind them),
+    // else from the image's lists again
     int base = 0;
-    for (int c = g + 1; c <= p.nseg; c += p.ngroups) base += class_nms_blockwide<THREADS>(p, b, c, gs, pool, base);
+    for (int c = g + 1; c <= p.nseg; c += p.ngroups) {
+      if (gs.cls_cnt[c] == 0) continue;   // (workgroup-uniform; cls_cnt is not touched below)
+      if (m <= YP_GROUP_KEYS) {
+        const LdsClassSrc lsrc{gs.a, m, c};
+        base += class_nms_blockwide<THREADS>(p, b, c, lsrc, gs, pool, base);
+      } else {
+        const PartSrc csrc{p.cand + (size_t)b * p.parts * p.cap_item, p.seg_count + (size_t)b * p.parts, p.parts, p.cap_item, c, 0, 0};
+        base += class_nms_blockwide<THREADS>(p, b, c, csrc, gs, pool, base);
+      }
+    }
+    const int want = min(p.max_dets, YP_SORT_MAX);
+    if (base > want) {
+      // cut the pooled list to the group's best max_dets (see step 6): read back from L2, where the
+      // write-through stores of all waves are once they have drained
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      const ListSrc ls{pool, base};
+      base = select_topk_sorted<THREADS>(ls, base, want, gs.sh, gs.stage, YP_GSTAGE_CAP);
+      if (t < base) store_wt(&pool[t], gs.sh.key[t]);
+    }
     if (t == 0) store_wt(&p.pool_count[(size_t)b * p.ngroups + g], base);
+    STAMP(7);
     return;
   }
   // 2. class offsets (exclusive prefix over the 256 possible class ids)
@@ -845,16 +910,11 @@ __device__ __forceinline__ void group_nms_body(const NmsArgs& p, int b, int g, G
   STAMP(4);
   // 5. Fast NMS inside every class: a candidate survives unless a higher-ranked box of its class
   //    overlaps it by more than the threshold (detection.py:221-234; every candidate has p > conf)
-  //    Class by class, the pairs (i < j) of a class dealt evenly to all threads: independent
-  //    iterations instead of one long chain of LDS round trips per candidate.
+  //    Class by class, the pairs (i < j) of a class dealt evenly to all threads (pair_sweep).
   for (int c = g + 1; c <= p.nseg; c += p.ngroups) {
     const int lo = gs.cls_off[c];
     const int kc = min(gs.cls_cnt[c], p.top_k);
-    const int npairs = tri_count(kc);
-    for (int x = t; x < npairs; x += THREADS) {
-      int i, j;
-      if (tri_pair(x, kc, i, j) && yp_iou_gt(gs.box[lo + i], gs.box[lo + j], p.nms_thresh)) gs.psup[lo + j] = 1;
-    }
+    pair_sweep<THREADS>(gs.box + lo, gs.psup + lo, kc, p.nms_thresh);
   }
   __syncthreads();
   STAMP(5);
@@ -867,9 +927,18 @@ __device__ __forceinline__ void group_nms_body(const NmsArgs& p, int b, int g, G
   }
   __syncthreads();
   STAMP(6);
-  // 6. the group's survivors, dense, for the cross-class selection (detection.py:234-239)
-  const int np = gs.npool;
-  for (int i = t; i < np; i += THREADS) store_wt(&pool[i], gs.bk[i]);
+  // 6. the group's survivors, dense, for the cross-class selection (detection.py:234-239).  Only a
+  //    group's best max_dets can be among the image's best max_dets: a longer list is cut to them here,
+  //    by all groups at once, so that the image's selection always fits its LDS stage.
+  int np = gs.npool;
+  const u64* out = gs.bk;
+  const int want = min(p.max_dets, YP_SORT_MAX);
+  if (np > want) {
+    const ListSrc ls{gs.bk, np};
+    np = select_topk_sorted<THREADS>(ls, np, want, gs.sh, nullptr, 0);   // (hist lies over box[], no longer needed)
+    out = gs.sh.key;
+  }
+  for (int i = t; i < np; i += THREADS) store_wt(&pool[i], out[i]);
   if (t == 0) store_wt(&p.pool_count[(size_t)b * p.ngroups + g], np);
   STAMP(7);
 }
