@@ -97,6 +97,13 @@ static int plan_handle(const yp_config& c, yp_handle* h) {
     // p_fgmax <= 1/(1+exp(x_bg-x_fgmax)) > conf  <=>  x_bg-x_fgmax < ln(1/conf-1); +1e-3 covers rounding
     const double cf = (double)c.conf_thresh;
     h->pre_thresh = cf > 0.0 ? (float)(log(1.0 / cf - 1.0) + 1e-3) : INFINITY;
+    // Second reject (score_filter.hip, phase 1): R >= 1/conf means p_fgmax <= conf.  Margins: 1e-3 relative
+    // for the hardware exp2, the products and the <= 1e-5 by which the computed probability can exceed the
+    // true one; an absolute one for the float sum behind the mean of the n = C-2 other logits: its error
+    // is at most (n-1) 2^-24 (xf - mean + |xf|), which moves the term n exp(mean - xf) by less than
+    // n^2 2^-24 (0.37 + |xf|); the kernel applies the test for |xf| <= 128 only, and the margin is twice that.
+    const double n = (double)c.num_classes - 2.0;
+    h->jen_thr = (cf > 0.0 && cf < 1.0 && n >= 1.0) ? (float)((1.0 / cf) * (1.0 + 1e-3) + 2.0 * n * n * 0x1p-24 * 128.37) : NAN;
   }
   {
     int cus = 0;
@@ -104,7 +111,6 @@ static int plan_handle(const yp_config& c, yp_handle* h) {
     h->num_cus = cus;
   }
   h->sf_bufb = (YP_SF_TA * h->lds_stride * (int)sizeof(float) + 15) / 16 * 16;
-  h->ntiles = (c.num_anchors + YP_SF_TA - 1) / YP_SF_TA;
   h->sf_waves_per_cu = yp_score_filter_waves_per_cu(h);
   {
     // Sum of probabilities <= 1 (+ rounding), so fewer than 1/conf classes of one anchor exceed conf.

@@ -122,7 +122,9 @@ __device__ __forceinline__ void yp_sanitize(float a, float b, float img_size, bo
 #endif  // __HIPCC__
 
 // ---- device scratch owned by a handle -----------------------------------------------------
-#define YP_SF_TA 32   // anchors per score_filter tile
+#ifndef YP_SF_TA
+#define YP_SF_TA 32   // anchors per score_filter tile (a multiple of 4, at most 32)
+#endif
 
 struct yp_scratch {
   u64* cand;            // [nitems][cap_item] candidate keys: score_filter item i (image i / parts, part
@@ -155,7 +157,7 @@ struct yp_handle {
   int sel_rows;         // min(max_dets, YP_SORT_MAX): rows a detection can land in
   int lds_stride;       // floats per anchor row in score_filter's LDS tile
   float pre_thresh;     // score_filter's early-reject bound on x_bg - x_fgmax
-  int ntiles;           // ceil(A / YP_SF_TA)
+  float jen_thr;        // score_filter's second reject: bound on 1 + exp(x_bg-xf) + (C-2) exp(mean-xf); NaN = off
   int num_cus;          // compute units of the device (256 on MI355X)
   int sf_bufb;          // score_filter: bytes of a wave's LDS tile buffer
   int sf_waves_per_cu;  // score_filter: single-wave workgroups resident per CU
@@ -175,16 +177,20 @@ struct yp_handle {
 // How score_filter cuts a batch into work items (and where the NMS kernels find their lists):
 // `parts` items per image, as many as keep every item resident at once, each a run of consecutive
 // tiles; an item's list holds at most cap_item keys.
+// (Tried: shrinking the tile to 29 anchors so that 95 items x 7 tiles cover A = 19248 instead of
+// 86 x 7 x 32 with ten idle wave slots per image - 49.1 us against 48.0: more resident waves do not help
+// this kernel, and tiles that start off a 16-byte boundary cost more than the balance gains.)
 static inline void yp_plan_items(const yp_handle* h, int batch, int* parts, long long* cap_item) {
+  const int ntiles = (h->cfg.num_anchors + YP_SF_TA - 1) / YP_SF_TA;
   const int resident = h->num_cus * h->sf_waves_per_cu;
   int pt = batch > 0 ? resident / batch : 1;
-  pt = pt < 1 ? 1 : (pt > h->ntiles ? h->ntiles : pt);
+  pt = pt < 1 ? 1 : (pt > ntiles ? ntiles : pt);
   // the longest item sets the kernel's length: keep its tile count, but use only as many items as
   // that needs, so that (nearly) all items are equally long (602 tiles: 86 x 7 instead of 96 x 6..7)
-  const int longest = (h->ntiles + pt - 1) / pt;
-  pt = (h->ntiles + longest - 1) / longest;
+  const int longest = (ntiles + pt - 1) / pt;
+  pt = (ntiles + longest - 1) / longest;
   *parts = pt;
-  *cap_item = (long long)((h->ntiles + pt - 1) / pt) * YP_SF_TA * h->keys_per_anchor;
+  *cap_item = (long long)longest * YP_SF_TA * h->keys_per_anchor;
 }
 
 // Per-class mode: the classes of an image are dealt round-robin to `ngroups` workgroups; a group's

@@ -25,6 +25,7 @@ struct ScoreFilterArgs {
   int fast;              // 1: stride == C and every tile starts 16-byte aligned -> wide-load path
   float conf, conf_lo;
   float pre_thresh;      // ln(1/conf - 1) + 1e-3: x_bg - x_fgmax must be below it to have p_fgmax > conf
+  float jen_thr, jen_n, jen_inv_n;   // second reject: (1/conf)(1+1e-3) + 0.1 (NaN = off), C-2, 1/(C-2)
 };
 
 // ---- cross-lane helpers: DPP moves inside a row of 16 lanes (one VALU op, no LDS round trip) ----
@@ -87,6 +88,9 @@ __device__ __forceinline__ int grp8_min(int v) {
   return v;
 }
 
+#ifndef YP_SF_MIN_WAVES
+#define YP_SF_MIN_WAVES 1   // waves per SIMD the register allocation must allow
+#endif
 #define YP_SF_KCAP 128   // keys the LDS hand-off buffer holds
 
 // One wave walks the tiles of its item.  Per tile of TA = 32 consecutive anchors (TA*C contiguous
@@ -106,11 +110,14 @@ __device__ __forceinline__ int grp8_min(int v) {
 //            anchors per round amortise the trees, the division and the bookkeeping over twice as
 //            many anchors as sixteen lanes per anchor did: the kernel is bound by instruction issue.
 //   phase 3  keys collect in LDS and leave in runs of >= 64 for the item's list
-template <int MODE, int CPL>
-__global__ __launch_bounds__(YP_WAVE) void score_filter_kernel(const ScoreFilterArgs p) {
+// FAST (compile time, so that no path exists on which staged loads are pending and nobody stores them):
+// rows are dense in LDS (stride == C) and the logits 16-byte aligned - the register-staged pipeline;
+// otherwise a plain element-wise tile copy.
+template <int MODE, int CPL, bool FAST>
+__global__ __launch_bounds__(YP_WAVE, YP_SF_MIN_WAVES) void score_filter_kernel(const ScoreFilterArgs p) {
   constexpr int TA = YP_SF_TA;
   constexpr int LPA = YP_WAVE / TA;   // lanes per anchor in phase 1
-  constexpr int NLD = (TA * CPL) / 32;   // 1 KiB wave-loads that cover TA rows of up to 8*CPL floats
+  constexpr int NLD = (TA * CPL + 31) / 32;   // 1 KiB wave-loads that cover TA rows of up to 8*CPL floats
   typedef float nat4 __attribute__((ext_vector_type(4)));
   extern __shared__ __align__(16) char lds_raw[];
   const int lane = threadIdx.x;
@@ -132,16 +139,19 @@ __global__ __launch_bounds__(YP_WAVE) void score_filter_kernel(const ScoreFilter
   const long long tile_bytes = (long long)TA * C * 4;
 
   nat4 stg[NLD];
-  // the tile's bytes as NLD non-temporal 16-byte loads per lane (read once, by nobody else); addresses
-  // past the tile's end are clamped to its last 16 bytes - those registers land in LDS nobody reads
-  auto issue_loads = [&](int bb, int tt) {
-    const int nbytes = min(TA, p.A - tt * TA) * C * 4;
+  // The tile's bytes as NLD non-temporal 16-byte buffer loads per lane (read once, by nobody else) through
+  // a descriptor of exactly the tile: lanes past its end get zeros from the range check - they land in LDS
+  // nobody reads - and with `on` false (no next tile) the descriptor has no records, so the same
+  // instructions fetch nothing.  The loads are thereby unconditional: one register set, no copies, and
+  // the compiler's wait for them sits at the LDS stores of the next iteration and nowhere else.
+  typedef unsigned int raw4 __attribute__((__vector_size__(4 * sizeof(unsigned int))));
+  auto issue_loads = [&](int bb, int tt, bool on) {
+    const int nbytes = on ? min(TA, p.A - tt * TA) * C * 4 : 0;
     const char* g = reinterpret_cast<const char*>(p.cls) + (bb * img_bytes + tt * tile_bytes);
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(g), 0, nbytes, 0x00020000);
 #pragma unroll
-    for (int u = 0; u < NLD; ++u) {
-      const int o = min(u * 1024 + lane16, nbytes - 16);
-      stg[u] = __builtin_nontemporal_load(reinterpret_cast<const nat4*>(g + o));
-    }
+    for (int u = 0; u < NLD; ++u)
+      stg[u] = __builtin_bit_cast(nat4, (raw4)__builtin_amdgcn_raw_buffer_load_b128(rsrc, lane16, u * 1024, 2 /* nt */));
   };
 
   for (int item = blockIdx.x; item < p.nitems; item += gridDim.x) {
@@ -159,18 +169,20 @@ __global__ __launch_bounds__(YP_WAVE) void score_filter_kernel(const ScoreFilter
       nout += nbuf;
       nbuf = 0;
     };
-    if (p.fast) issue_loads(b, t_begin);
+    if (FAST) issue_loads(b, t_begin, t_begin < t_end);
 
     for (int tix = t_begin; tix < t_end; ++tix) {
       const int a0 = tix * TA;
       const int na = min(TA, p.A - a0);
       // ---- phase 0 ------------------------------------------------------------------------------
-      if (p.fast) {
+      if (FAST) {
+        // all NLD registers, unconditionally (the buffer has NLD KiB): a store the compiler cannot see
+        // happen would leave it unsure whether the load behind the register has landed, and it would
+        // then wait in phase 1 - on the loads just issued for the next tile
         nat4* const t4 = reinterpret_cast<nat4*>(tile);
 #pragma unroll
-        for (int u = 0; u < NLD; ++u)
-          if (u * 1024 + lane16 < p.bufb) t4[u * YP_WAVE + lane] = stg[u];
-        if (tix + 1 < t_end) issue_loads(b, tix + 1);
+        for (int u = 0; u < NLD; ++u) t4[u * YP_WAVE + lane] = stg[u];
+        issue_loads(b, min(tix + 1, t_end - 1), tix + 1 < t_end);
       } else {
         const int nelem = na * C;
         const float* __restrict__ src = p.cls + ((size_t)b * p.A + a0) * C;
@@ -190,6 +202,7 @@ __global__ __launch_bounds__(YP_WAVE) void score_filter_kernel(const ScoreFilter
         const float* row = tile + min(al1, na - 1) * p.stride;
         const float x0 = row[0];
         float xf = -INFINITY;
+        yp_f2 s2 = {0.0f, 0.0f};                         // sum of this lane's foreground logits (for the second reject)
         int c0 = 1 + q;
         for (; c0 + LPA * 15 < C; c0 += 16 * LPA) {     // full chunks: base + immediate offsets
           float v[16];
@@ -198,7 +211,10 @@ __global__ __launch_bounds__(YP_WAVE) void score_filter_kernel(const ScoreFilter
           const float t0 = max3f(v[0], v[1], v[2]), t1 = max3f(v[3], v[4], v[5]), t2 = max3f(v[6], v[7], v[8]);
           const float t3 = max3f(v[9], v[10], v[11]), t4 = max3f(v[12], v[13], v[14]);
           xf = max3f(max3f(t0, t1, t2), max3f(t3, t4, v[15]), xf);
+#pragma unroll
+          for (int jj = 0; jj < 16; jj += 2) s2 = s2 + (yp_f2){v[jj], v[jj + 1]};
         }
+        float dup = 0.0f;                               // the tail's clamped reads, all of class C-1, counted once too often
         if (c0 < C) {                                   // ragged tail, clamped
           float v[16];
 #pragma unroll
@@ -206,10 +222,29 @@ __global__ __launch_bounds__(YP_WAVE) void score_filter_kernel(const ScoreFilter
           const float t0 = max3f(v[0], v[1], v[2]), t1 = max3f(v[3], v[4], v[5]), t2 = max3f(v[6], v[7], v[8]);
           const float t3 = max3f(v[9], v[10], v[11]), t4 = max3f(v[12], v[13], v[14]);
           xf = max3f(max3f(t0, t1, t2), max3f(t3, t4, v[15]), xf);
+#pragma unroll
+          for (int jj = 0; jj < 16; jj += 2) s2 = s2 + (yp_f2){v[jj], v[jj + 1]};
+          dup = (float)(16 - (C - c0 + LPA - 1) / LPA) * v[15];
         }
+        float sfg = (s2.x + s2.y) - dup;
         xf = fmaxf(xf, dpp_f<YP_DPP_XOR1>(xf));
+        sfg = sfg + dpp_f<YP_DPP_XOR1>(sfg);
+        if (LPA >= 4) {
+          xf = fmaxf(xf, dpp_f<YP_DPP_XOR2>(xf));
+          sfg = sfg + dpp_f<YP_DPP_XOR2>(sfg);
+        }
         m = fmaxf(x0, xf);
         pre = (al1 < na) && (q == 0) && ((x0 - xf) < p.pre_thresh);
+        // Second exact-safe reject (Jensen): the C-2 foreground classes other than the best one have
+        // sum exp(x_c) >= (C-2) exp(mean x_c), so 1/p_fgmax >= R = 1 + exp(x_bg-xf) + (C-2) exp(mean-xf),
+        // and R >= 1/conf (plus margins, yp_create) means no class of the anchor can pass.  The margins
+        // cover the float sum behind `mean` for |xf| <= 128 (its error grows with the logits' size).
+        // jen_thr is NaN when the test is off: the comparison is then false.
+        {
+          const float mu_f = (sfg - xf) * p.jen_inv_n - xf;                       // mean of the others, minus xf (<= 0)
+          const float r = 1.0f + __builtin_amdgcn_exp2f((x0 - xf) * 1.44269504f) + p.jen_n * __builtin_amdgcn_exp2f(mu_f * 1.44269504f);
+          pre = pre && !((r >= p.jen_thr) && (fabsf(xf) <= 128.0f));
+        }
       }
       const u64 pm = __ballot(pre);
       const int npass = __popcll(pm);
@@ -252,6 +287,7 @@ __global__ __launch_bounds__(YP_WAVE) void score_filter_kernel(const ScoreFilter
         const bool lead = surv && j == 0;
         const u64 bl = __ballot(lead);
         nsurv += __popcll(bl);
+        if (bl == 0) continue;   // (wave-uniform) nobody in this round passed: nothing to emit
         if (MODE == YP_NMS_CROSS_CLASS) {
           // tf.argmax over the probabilities (detection.py:184): the FIRST class whose rounded
           // probability equals the maximum.  Only an e_c within 2^-21 of the largest can round to it;
@@ -333,9 +369,9 @@ __global__ __launch_bounds__(YP_WAVE) void score_filter_kernel(const ScoreFilter
   }   // item loop
 }
 
-template <int MODE>
+template <int MODE, bool FAST>
 static const void* kernel_for(int cpl) {
-#define YP_SF_CASE(N) case N: return reinterpret_cast<const void*>(&score_filter_kernel<MODE, N>);
+#define YP_SF_CASE(N) case N: return reinterpret_cast<const void*>(&score_filter_kernel<MODE, N, FAST>);
   switch (cpl) {
     YP_SF_CASE(2) YP_SF_CASE(4) YP_SF_CASE(6) YP_SF_CASE(8) YP_SF_CASE(10) YP_SF_CASE(11) YP_SF_CASE(12)
     YP_SF_CASE(14) YP_SF_CASE(16) YP_SF_CASE(20) YP_SF_CASE(24) YP_SF_CASE(32)
@@ -352,11 +388,18 @@ static int classes_per_lane(int C) {
   return 32;
 }
 
-static size_t lds_bytes(const yp_handle* h) { return (size_t)h->sf_bufb + YP_WAVE * sizeof(int2) + YP_SF_KCAP * sizeof(u64); }
+// Bytes of a wave's LDS tile: the tile itself, and at least the NLD KiB that phase 0 writes without
+// looking (all NLD staged wave-loads, also the clamped ones past the tile's end).
+static int tile_lds_bytes(const yp_handle* h) {
+  const int nld = (YP_SF_TA * classes_per_lane(h->cfg.num_classes) + 31) / 32;
+  return h->sf_bufb > nld * 1024 ? h->sf_bufb : nld * 1024;
+}
+static size_t lds_bytes(const yp_handle* h) { return (size_t)tile_lds_bytes(h) + YP_WAVE * sizeof(int2) + YP_SF_KCAP * sizeof(u64); }
 
-static const void* kernel_of(const yp_handle* h) {
+static const void* kernel_of(const yp_handle* h, bool fast = true) {
   const int cpl = classes_per_lane(h->cfg.num_classes);
-  return h->cfg.nms_mode == YP_NMS_CROSS_CLASS ? kernel_for<YP_NMS_CROSS_CLASS>(cpl) : kernel_for<YP_NMS_PER_CLASS>(cpl);
+  if (h->cfg.nms_mode == YP_NMS_CROSS_CLASS) return fast ? kernel_for<YP_NMS_CROSS_CLASS, true>(cpl) : kernel_for<YP_NMS_CROSS_CLASS, false>(cpl);
+  return fast ? kernel_for<YP_NMS_PER_CLASS, true>(cpl) : kernel_for<YP_NMS_PER_CLASS, false>(cpl);
 }
 
 // Single-wave workgroups of this handle's kernel that one CU holds at once: the smaller of the
@@ -380,13 +423,14 @@ hipError_t yp_launch_score_filter(const yp_handle* h, int batch, const float* pr
   a.conf = h->cfg.conf_thresh;
   a.conf_lo = h->cfg.conf_thresh * (1.0f - 0x1p-20f);
   a.pre_thresh = h->pre_thresh;
-  a.ntiles = h->ntiles;
+  a.jen_thr = h->jen_thr; a.jen_n = (float)(a.C - 2); a.jen_inv_n = a.C > 2 ? 1.0f / (float)(a.C - 2) : 0.0f;
+  a.ntiles = (a.A + YP_SF_TA - 1) / YP_SF_TA;
   yp_plan_items(h, batch, &a.parts, &a.cap_item);
   a.nitems = batch * a.parts;
-  a.bufb = h->sf_bufb;
+  a.bufb = tile_lds_bytes(h);
   a.fast = (a.stride == a.C) && (((long long)a.A * a.C) % 4 == 0) && ((((uintptr_t)pred_cls) & 15u) == 0);
   const int resident = h->num_cus * h->sf_waves_per_cu;
   const dim3 grid(a.nitems < resident ? a.nitems : resident);
   void* args[] = {&a};
-  return hipLaunchKernel(kernel_of(h), grid, dim3(YP_WAVE), args, lds_bytes(h), st);
+  return hipLaunchKernel(kernel_of(h, a.fast != 0), grid, dim3(YP_WAVE), args, lds_bytes(h), st);
 }
