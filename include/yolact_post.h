@@ -179,7 +179,7 @@ int yp_masks_to_rle(int32_t device_id, int32_t batch, int32_t max_dets, int32_t 
                     uint8_t* bitmaps, uint32_t* rle_counts, int32_t* rle_len, int32_t rle_cap,
                     void* hip_stream);
 
-/* ---- mask assembly of the training loss (FORWARD ONLY, no gradient) ----
+/* ---- mask assembly of the training loss (forward - the gradients follow below) ----
  * loss/loss_yolact.py:239-253 (YOLACTLoss._loss_mask): mask_p = sigmoid(proto_out[i] @ pos_coef^T),
  * cropped by the positives' prior boxes (pixels, normalised by img_h / img_w at L247-252) with the
  * same utils.crop as Detect (L253), for every image of the batch in one launch of kernel 4.
@@ -192,6 +192,24 @@ int yp_assemble_masks(int32_t device_id, int32_t batch, int32_t rows, int32_t pr
                       int32_t img_h, int32_t img_w, int32_t use_cropped_mask,
                       const float* proto, const float* coef, const float* boxes, const int32_t* num_rows,
                       float* crop_workspace, float* out_masks, void* hip_stream);
+
+/* ---- gradients of that mask assembly (backward) ----
+ * The reference has no code of its own here: TensorFlow's autodiff differentiates loss/loss_yolact.py:239-253
+ * (tf.linalg.matmul L239, tf.sigmoid L241, utils.crop L253).  Given the forward's output `masks` and
+ * grad_masks = dL/dmasks (both [batch,rows,ph,pw]):   dz = (g * m) * (1 - m)   (SigmoidGrad; m is 0 outside
+ * the crop box, and so is dz);   grad_proto[b,p,k] = sum_n dz[n,p] coef[b,n,k];   grad_coef[b,n,k] =
+ * sum_p dz[n,p] proto[b,p,k];   grad_coef of rows >= num_rows[b] is 0.  `masks` must be yp_assemble_masks'
+ * output for the same proto / coef / boxes / num_rows (only the pixels inside a row's box are read).
+ * Deterministic: fixed summation orders, no float atomics (csrc/loss_grad.hip states them;
+ * oracle/detect_oracle.c restates them, and the GPU tests compare bit for bit).
+ *   grad_proto [batch,ph,pw,32]   grad_coef [batch,rows,32]   crop_workspace [batch,rows,4] as above.
+ * All device pointers; proto, coef, boxes, crop_workspace, grad_proto 16-byte aligned; asynchronous on
+ * hip_stream; allocates nothing. */
+int yp_assemble_masks_backward(int32_t device_id, int32_t batch, int32_t rows, int32_t proto_h, int32_t proto_w,
+                               int32_t img_h, int32_t img_w, int32_t use_cropped_mask,
+                               const float* proto, const float* coef, const float* boxes, const int32_t* num_rows,
+                               const float* masks, const float* grad_masks,
+                               float* crop_workspace, float* grad_proto, float* grad_coef, void* hip_stream);
 
 /* pycocotools' compressed counts string (maskApi.c rleToString, what mask.encode puts in
  * rle['counts'], coco_eval.py:136-137) of n HOST counts.  Writes at most cap-1 characters and a

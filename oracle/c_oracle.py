@@ -43,6 +43,8 @@ def lib():
         L.yo_softmax_row.argtypes = [fp, ctypes.c_int, fp]
         L.yo_loss_masks.restype = None
         L.yo_loss_masks.argtypes = [ctypes.c_int] * 7 + [fp] * 4
+        L.yo_loss_masks_backward.restype = None
+        L.yo_loss_masks_backward.argtypes = [ctypes.c_int] * 4 + [fp] * 6
         L.yo_cpu_ok.restype = ctypes.c_int
         if not L.yo_cpu_ok():
             raise RuntimeError("oracle library needs a CPU with FMA")
@@ -99,3 +101,17 @@ def loss_masks(proto, pos_coef, pos_box, img_h, img_w, use_cropped_mask=True):
     out = np.zeros((n, ph, pw), np.float32)
     L.yo_loss_masks(n, K, ph, pw, int(img_h), int(img_w), 1 if use_cropped_mask else 0, _p(proto), _p(pos_coef), _p(pos_box), _p(out))
     return out
+
+
+def loss_masks_backward(proto, pos_coef, masks, grad_masks):
+    """Gradients of loss/loss_yolact.py:239-253 for one image, in the HIP kernels' summation order:
+    proto [ph,pw,K], pos_coef [n,K], masks / grad_masks [n,ph,pw] -> (grad_proto [ph,pw,K], grad_coef [n,K])."""
+    L = lib()
+    proto = np.ascontiguousarray(proto, np.float32); pos_coef = np.ascontiguousarray(pos_coef, np.float32)
+    masks = np.ascontiguousarray(masks, np.float32); grad_masks = np.ascontiguousarray(grad_masks, np.float32)
+    ph, pw, K = proto.shape
+    n = pos_coef.shape[0]
+    gp = np.zeros((ph, pw, K), np.float32)
+    gc = np.zeros((n, K), np.float32)
+    L.yo_loss_masks_backward(n, K, ph, pw, _p(proto), _p(pos_coef), _p(masks), _p(grad_masks), _p(gp), _p(gc))
+    return gp, gc

@@ -357,6 +357,52 @@ void yo_loss_masks(int num_pos, int K, int ph, int pw, int img_h, int img_w, int
   }
 }
 
+/* ---------------------------------------------------------------------------------------------
+ * Gradients of that mask assembly w.r.t. proto and pos_coef, given dL/d mask_p.
+ * The reference has no code for this step - TensorFlow's autodiff differentiates L239-253:
+ *   crop (a product with a constant 0/1 mask): g passes inside the box, 0 outside;
+ *   tf.sigmoid: SigmoidGrad = dy * y * (1 - y);   tf.linalg.matmul: dA = dC B, dB = A^T dC.
+ * Since the cropped forward output is 0 outside the box, dz = (g * m) * (1 - m) with m = mask_p as the
+ * forward returned it covers the crop too.  TF does not fix a summation order; the HIP kernels do, and
+ * this restatement follows them so that the comparison can be bit-exact (YP-MATH, fp-contract off):
+ *   grad_proto[p][k] = fmaf chain over r = 0..num_pos-1 (ascending) of dz[r][p] * pos_coef[r][k]
+ *   grad_coef[r][k]  = YO_GC_STREAMS partial fmaf chains - stream s takes the pixel rows y with
+ *                      y % YO_GC_STREAMS == s, in (y, x) ascending order, of dz[r][p] * proto[p][k] - added
+ *                      up in stream order, starting from stream 0's value.
+ * Terms with dz == 0 change nothing (finite inputs), so the kernels skip the pixels outside the box.
+ */
+#define YO_GC_STREAMS 16
+void yo_loss_masks_backward(int num_pos, int K, int ph, int pw, const float* proto, const float* pos_coef,
+                            const float* masks, const float* grad_masks, float* grad_proto, float* grad_coef) {
+  const size_t P = (size_t)ph * pw;
+  for (size_t p = 0; p < P; ++p)
+    for (int k = 0; k < K; ++k) {
+      float acc = 0.0f;
+      for (int r = 0; r < num_pos; ++r) {
+        const float m = masks[(size_t)r * P + p], g = grad_masks[(size_t)r * P + p];
+        const float dz = (g * m) * (1.0f - m);
+        acc = fmaf(dz, pos_coef[(size_t)r * K + k], acc);
+      }
+      grad_proto[p * K + k] = acc;
+    }
+  for (int r = 0; r < num_pos; ++r)
+    for (int k = 0; k < K; ++k) {
+      float total = 0.0f;
+      for (int s = 0; s < YO_GC_STREAMS; ++s) {
+        float acc = 0.0f;
+        for (int y = s; y < ph; y += YO_GC_STREAMS)
+          for (int x = 0; x < pw; ++x) {
+            const size_t p = (size_t)y * pw + x;
+            const float m = masks[(size_t)r * P + p], g = grad_masks[(size_t)r * P + p];
+            const float dz = (g * m) * (1.0f - m);
+            acc = fmaf(dz, proto[p * K + k], acc);
+          }
+        total = s == 0 ? acc : total + acc;
+      }
+      grad_coef[(size_t)r * K + k] = total;
+    }
+}
+
 int yo_has_openmp(void) {
 #ifdef _OPENMP
   return 1;

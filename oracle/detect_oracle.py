@@ -336,6 +336,18 @@ def loss_mask_assembly(proto: np.ndarray, pos_coef: np.ndarray, pos_prior_box: n
     return np.transpose(mask_p, (2, 0, 1))
 
 
+def loss_mask_assembly_backward(proto: np.ndarray, pos_coef: np.ndarray, masks: np.ndarray, grad_masks: np.ndarray):
+    """Gradients of loss_mask_assembly w.r.t. proto and pos_coef given dL/d mask_p [n,ph,pw].  The reference
+    leaves this to TensorFlow's autodiff of loss/loss_yolact.py:239-253: the crop passes the gradient inside
+    the box only, SigmoidGrad = dy*y*(1-y), matmul: dA = dC B, dB = A^T dC.  With the cropped forward output
+    `masks` (0 outside the box) that is dz = g*m*(1-m).  Plain matrix products in the arrays' dtype (pass
+    float64 for a tolerance check; the summation order of the HIP kernels is restated in detect_oracle.c)."""
+    dz = grad_masks * masks * (1.0 - masks)                                        # [n,ph,pw]
+    grad_proto = np.einsum('nyx,nk->yxk', dz, pos_coef)
+    grad_coef = np.einsum('nyx,yxk->nk', dz, proto)
+    return grad_proto, grad_coef
+
+
 # --------------------------------------------------------------------------
 # data/anchor.py (produces `priors`)
 # --------------------------------------------------------------------------

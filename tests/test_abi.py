@@ -128,22 +128,23 @@ def test_make_priors_size_query_and_errors():
 
 
 def test_pair_enumeration_used_by_the_nms_kernels():
-    """csrc/nms.hip tri_pair(): the n(n-1)/2 unordered pairs of n boxes as a rectangle of n rows and
-    n/2 columns, row r and column c pairing r with (r+1+c) mod n, the row recovered from the flat index
-    with one float multiply.  Restated here with the same float32 operations: every pair exactly once
-    for every n the kernels can meet (top_k <= 256)."""
-    import numpy as np
-    f32 = np.float32
-    for n in range(0, 258):
-        w = n >> 1
-        seen = set()
-        for x in range(n * w):
-            r = int(f32((f32(x) + f32(0.5)) * (f32(1.0) / f32(w))))
-            c = x - r * w
-            q = r + 1 + c
-            q = q - n if q >= n else q
-            if (n & 1) or c < w - 1 or r < w:
-                pr = (min(r, q), max(r, q))
-                assert pr[0] != pr[1] and pr not in seen, (n, x)
-                seen.add(pr)
-        assert len(seen) == n * (n - 1) // 2, n
+    """csrc/nms.hip pair_sweep(): column j of the Fast NMS triangle has the j rows i < j; columns f and
+    k-1-f are folded into one of k-1 rows, cut into G parts of L rows, one (folded column, part) per
+    thread.  Restated here with the same integer arithmetic: every pair (i, j), i < j, exactly once, for
+    every k the kernels can meet (top_k <= 256) and both workgroup sizes."""
+    for threads in (512, 1024):
+        for k in range(0, 258):
+            seen = set()
+            if k >= 2:
+                nf = (k + 1) >> 1
+                G = max(1, threads // nf)
+                L = (k - 1 + G - 1) // G
+                for s in range(nf * G):
+                    part, f = divmod(s, nf)
+                    jb = k - 1 - f
+                    rows = f + (jb if jb != f else 0)
+                    for v in range(part * L, min(part * L + L, rows)):
+                        pr = (v, f) if v < f else (v - f, jb)
+                        assert pr[0] < pr[1] and pr not in seen, (k, s, v)
+                        seen.add(pr)
+            assert len(seen) == k * (k - 1) // 2, (threads, k)

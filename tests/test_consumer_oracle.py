@@ -81,3 +81,33 @@ def test_threshold_orders_differ_only_near_edges():
     assert a.shape == b.shape == (96, 96) and set(np.unique(a)) <= {0, 1} and set(np.unique(b)) <= {0, 1}
     assert 0 < (a != b).mean() < 0.05 and abs(int(a.sum()) - int(b.sum())) < 0.05 * a.sum()
     _ = rng
+
+
+def test_loss_mask_backward_oracle_against_finite_differences():
+    """The F4 backward oracle (no reference code exists for it: TF autodiff) is pinned to the forward oracle
+    by central differences in float64, and the C restatement (kernel summation order, float32) to the float64
+    analytic form."""
+    from oracle import c_oracle, detect_oracle as po
+    rng = np.random.default_rng(3)
+    ph, pw, K, n = 14, 17, 32, 6
+    proto = np.maximum(0, rng.normal(0, 1, (ph, pw, K)))
+    coef = 0.3 * np.tanh(rng.normal(0, 1, (n, K)))
+    box = np.stack([rng.uniform(0, 30, n), rng.uniform(0, 30, n), rng.uniform(40, 100, n), rng.uniform(40, 100, n)], -1)
+    g = rng.normal(0, 1, (n, ph, pw))
+    fwd = lambda pr, cf: po.loss_mask_assembly(pr, cf, box, 100.0, 100.0)
+    m = fwd(proto, coef)
+    gp, gc = po.loss_mask_assembly_backward(proto, coef, m, g)
+    eps = 1e-6
+    for _ in range(12):
+        i = tuple(int(rng.integers(0, s)) for s in coef.shape)
+        d = np.zeros_like(coef); d[i] = eps
+        fd = ((fwd(proto, coef + d) - fwd(proto, coef - d)) * g).sum() / (2 * eps)
+        assert abs(fd - gc[i]) <= 1e-6 * max(1.0, abs(fd))
+        j = tuple(int(rng.integers(0, s)) for s in proto.shape)
+        d = np.zeros_like(proto); d[j] = eps
+        fd = ((fwd(proto + d, coef) - fwd(proto - d, coef)) * g).sum() / (2 * eps)
+        assert abs(fd - gp[j]) <= 1e-6 * max(1.0, abs(fd))
+    f4 = [x.astype(np.float32) for x in (proto, coef, m, g)]
+    cp, cc = c_oracle.loss_masks_backward(*f4)
+    ap, ac = po.loss_mask_assembly_backward(*[x.astype(np.float64) for x in f4])
+    assert np.abs(cp - ap).max() <= 1e-5 and np.abs(cc - ac).max() <= 1e-4

@@ -168,3 +168,68 @@ def test_loss_mask_assembly_forward(use_crop):
             if b == 0:
                 refn = po.loss_mask_assembly(proto[b], coef[b, :n], boxes[b, :n], H, W, use_crop)
                 assert np.abs(got[b, :n] - refn).max() <= 1e-5
+
+
+@pytest.mark.parametrize("use_crop", [True, False])
+def test_loss_mask_assembly_backward(use_crop):
+    """SURVEY.md 8f F4, backward: gradients w.r.t. proto and pos_coef of loss/loss_yolact.py:239-253 (the
+    reference leaves them to TF autodiff).  Bit-exact against the C restatement of the kernels' summation
+    order, within 1e-5 (relative to the sum of the terms' magnitudes) of the float64 analytic gradient, rows
+    beyond num_pos get zero coefficient gradients, and two runs give identical bits (no float atomics)."""
+    import torch
+    from oracle import c_oracle, detect_oracle as po
+    from yolact_amd import consumer
+    rng = np.random.default_rng(22)
+    for (B, rows, ph, pw, H, W) in ((2, 7, 12, 12, 64, 64), (5, 100, 23, 31, 550, 550), (1, 40, 138, 138, 550, 550)):
+        proto = np.maximum(0, rng.normal(0, 1, (B, ph, pw, 32))).astype(np.float32)
+        coef = (0.3 * np.tanh(rng.normal(0, 1, (B, rows, 32)))).astype(np.float32)
+        y1 = rng.uniform(-20, H, (B, rows)); x1 = rng.uniform(-20, W, (B, rows))
+        boxes = np.stack([y1, x1, y1 + rng.uniform(-5, H / 2, (B, rows)), x1 + rng.uniform(-5, W / 2, (B, rows))], -1).astype(np.float32)
+        npos = rng.integers(0, rows + 1, B).astype(np.int32); npos[0] = rows
+        grad = rng.normal(0, 1, (B, rows, ph, pw)).astype(np.float32)
+        t = [torch.from_numpy(x).cuda() for x in (proto, coef, boxes, npos)]
+        masks = consumer.assemble_loss_masks(*t, (H, W), use_cropped_mask=use_crop)
+        gp, gc = consumer.assemble_loss_masks_backward(*t, masks, torch.from_numpy(grad).cuda(), (H, W), use_cropped_mask=use_crop)
+        gp2, gc2 = consumer.assemble_loss_masks_backward(*t, masks, torch.from_numpy(grad).cuda(), (H, W), use_cropped_mask=use_crop)
+        torch.cuda.synchronize()
+        assert torch.equal(gp, gp2) and torch.equal(gc, gc2)
+        gp, gc, m = gp.cpu().numpy(), gc.cpu().numpy(), masks.cpu().numpy()
+        for b in range(B):
+            n = int(npos[b])
+            rp, rc = c_oracle.loss_masks_backward(proto[b], coef[b, :n], m[b, :n], grad[b, :n])
+            assert np.array_equal(gp[b].view(np.uint32), rp.view(np.uint32)), (B, rows, b, np.abs(gp[b] - rp).max())
+            assert np.array_equal(gc[b, :n].view(np.uint32), rc.view(np.uint32)), (B, rows, b, np.abs(gc[b, :n] - rc).max())
+            assert not gc[b, n:].any()
+            if b == 0:
+                f8 = [x.astype(np.float64) for x in (proto[b], coef[b, :n], m[b, :n], grad[b, :n])]
+                ap, ac = po.loss_mask_assembly_backward(*f8)
+                dz = np.abs(f8[3] * f8[2] * (1 - f8[2]))
+                sp = np.einsum('nyx,nk->yxk', dz, np.abs(f8[1])) + 1e-30
+                sc = np.einsum('nyx,yxk->nk', dz, np.abs(f8[0])) + 1e-30
+                assert (np.abs(gp[b] - ap) / sp).max() <= 1e-5 and (np.abs(gc[b, :n] - ac) / sc).max() <= 1e-5
+
+
+def test_loss_mask_assembly_autograd():
+    """LossMaskAssembly: a BCE-style loss on the assembled masks back-propagates to proto and pos_coef; the
+    gradients agree with torch autograd through a plain torch restatement of the forward."""
+    import torch
+    from yolact_amd import consumer
+    g = torch.Generator().manual_seed(5)
+    B, rows, ph, pw, H, W = 3, 11, 24, 20, 96, 80
+    proto = torch.relu(torch.randn(B, ph, pw, 32, generator=g)).cuda().requires_grad_(True)
+    coef = (0.3 * torch.tanh(torch.randn(B, rows, 32, generator=g))).cuda().requires_grad_(True)
+    y1 = torch.rand(B, rows, generator=g) * H * 0.6; x1 = torch.rand(B, rows, generator=g) * W * 0.6
+    boxes = torch.stack([y1, x1, y1 + 8 + torch.rand(B, rows, generator=g) * H * 0.4, x1 + 8 + torch.rand(B, rows, generator=g) * W * 0.4], -1).cuda()
+    npos = torch.tensor([rows, 4, 0], dtype=torch.int32).cuda()
+    target = (torch.rand(B, rows, ph, pw, generator=g) > 0.5).float().cuda()
+    masks = consumer.LossMaskAssembly.apply(proto, coef, boxes, npos, H, W, True)
+    loss = ((masks - target) ** 2).sum()
+    loss.backward()
+    gp, gc = proto.grad.clone(), coef.grad.clone()
+    proto.grad = None; coef.grad = None
+    # plain torch: sigmoid(proto @ coef^T) times the 0/1 crop the kernel applied (taken from its output)
+    inside = (masks.detach() != 0).float()
+    ref = torch.sigmoid(torch.einsum('byxk,bnk->bnyx', proto, coef)) * inside
+    ((ref - target) ** 2 * inside + (1 - inside) * target ** 2).sum().backward()
+    assert torch.allclose(gp, proto.grad, rtol=1e-4, atol=1e-4) and torch.allclose(gc, coef.grad, rtol=1e-4, atol=1e-3)
+    assert not gc[2].any() and not gc[1, 4:].any()

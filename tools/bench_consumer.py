@@ -54,6 +54,51 @@ def main():
         co.rle_counts(co.mask_to_bitmap(m[i], cfg.img_h, cfg.img_w))
     t = time.perf_counter() - t0
     res["cpu_numpy_restatement"] = {"detections_per_s": round(16 / t, 1), "sample": "16 detections, one core"}
+    # F4: the loss's mask assembly, forward and backward, at the same shape (32 images x 100 positives, boxes
+    # = the detections' boxes in pixels)
+    boxes_px = (out["detection_boxes"] * torch.tensor([cfg.img_h, cfg.img_w, cfg.img_h, cfg.img_w], device="cuda", dtype=torch.float32)).contiguous()
+    coef = d["pred_mask_coef"][:, :cfg.max_dets].contiguous()
+    npos = out["num_detections"].to(torch.int32).contiguous()
+    proto = d["proto_out"].contiguous()
+    masks = consumer.assemble_loss_masks(proto, coef, boxes_px, npos, (cfg.img_h, cfg.img_w))
+    grad = torch.randn_like(masks)
+    torch.cuda.synchronize()
+
+    def timed(fn, reps=10):
+        fn(); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record(); torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+    fwd_ms = timed(lambda: consumer.assemble_loss_masks(proto, coef, boxes_px, npos, (cfg.img_h, cfg.img_w), out=masks))
+    bwd_ms = timed(lambda: consumer.assemble_loss_masks_backward(proto, coef, boxes_px, npos, masks, grad, (cfg.img_h, cfg.img_w)))
+    inside = float((masks != 0).float().mean())
+
+    def torch_ref():
+        z = torch.einsum('byxk,bnk->bnyx', proto, coef)
+        m = torch.sigmoid(z)
+        dz = grad * m * (1 - m)
+        return torch.einsum('bnyx,bnk->byxk', dz, coef), torch.einsum('bnyx,byxk->bnk', dz, proto)
+    ref_ms = timed(torch_ref, reps=3)
+    # the same with boxes of a training set's size: sides uniform in 10-60 % of the image (~12 % of the pixels inside)
+    g = torch.Generator().manual_seed(0)
+    hh = (0.1 + 0.5 * torch.rand(B, cfg.max_dets, generator=g)) * cfg.img_h
+    ww = (0.1 + 0.5 * torch.rand(B, cfg.max_dets, generator=g)) * cfg.img_w
+    y1 = torch.rand(B, cfg.max_dets, generator=g) * (cfg.img_h - hh)
+    x1 = torch.rand(B, cfg.max_dets, generator=g) * (cfg.img_w - ww)
+    big = torch.stack([y1, x1, y1 + hh, x1 + ww], -1).cuda().contiguous()
+    full = torch.full((B,), cfg.max_dets, dtype=torch.int32, device="cuda")
+    masks_big = consumer.assemble_loss_masks(proto, coef, big, full, (cfg.img_h, cfg.img_w))
+    fwd_big = timed(lambda: consumer.assemble_loss_masks(proto, coef, big, full, (cfg.img_h, cfg.img_w), out=masks_big))
+    bwd_big = timed(lambda: consumer.assemble_loss_masks_backward(proto, coef, big, full, masks_big, grad, (cfg.img_h, cfg.img_w)))
+    res["loss_mask_assembly_large_boxes"] = {"forward_ms": round(fwd_big, 4), "backward_ms": round(bwd_big, 4), "rows": B * cfg.max_dets,
+                                             "fraction_of_pixels_inside_boxes": round(float((masks_big != 0).float().mean()), 4)}
+    res["loss_mask_assembly"] = {"forward_ms": round(fwd_ms, 4), "backward_ms": round(bwd_ms, 4), "rows": int(npos.sum()),
+                                 "fraction_of_pixels_inside_boxes": round(inside, 4),
+                                 "torch_rocblas_forward_plus_backward_ms": round(ref_ms, 4),
+                                 "note": "torch leg: dense einsum/sigmoid on the same GPU, no crop, for scale only"}
     print(json.dumps({"workload": "config 2: 32 images x 100 detections, 138x138 -> 550x550", **res}))
 
 

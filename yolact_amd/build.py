@@ -8,7 +8,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.join(HERE, "libyolact_post.so")
-SOURCES = ["api.hip", "score_filter.hip", "nms.hip", "mask.hip", "priors.hip", "rle.hip"]
+SOURCES = ["api.hip", "score_filter.hip", "nms.hip", "mask.hip", "priors.hip", "rle.hip", "loss_grad.hip"]
 HEADERS = ["common.hpp", os.path.join("..", "..", "include", "yolact_post.h")]
 # -ffp-contract=off: YP-MATH writes every fma explicitly.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",

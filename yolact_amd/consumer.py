@@ -116,7 +116,8 @@ def assemble_loss_masks(proto: torch.Tensor, pos_coef: torch.Tensor, pos_prior_b
                         img_hw, use_cropped_mask: bool = True, out: torch.Tensor | None = None) -> torch.Tensor:
     """Forward mask assembly of the training loss (``loss/loss_yolact.py:239-253``) for a whole batch:
     proto [B,ph,pw,32], pos_coef [B,rows,32], pos_prior_box [B,rows,4] yxyx pixels, num_pos [B] int32 ->
-    [B,rows,ph,pw] float32 (rows >= num_pos[b] are zeros).  Forward only: no gradient is recorded."""
+    [B,rows,ph,pw] float32 (rows >= num_pos[b] are zeros).  No gradient is recorded here: LossMaskAssembly
+    below is the differentiable form."""
     B, ph, pw, K = proto.shape
     rows = pos_coef.shape[1]
     dev = proto.device
@@ -132,3 +133,48 @@ def assemble_loss_masks(proto: torch.Tensor, pos_coef: torch.Tensor, pos_prior_b
                                              proto.data_ptr(), pos_coef.data_ptr(), pos_prior_box.data_ptr(), num_pos.data_ptr(),
                                              ws.data_ptr(), out.data_ptr(), ctypes.c_void_p(stream)))
     return out
+
+
+def assemble_loss_masks_backward(proto: torch.Tensor, pos_coef: torch.Tensor, pos_prior_box: torch.Tensor, num_pos: torch.Tensor,
+                                 masks: torch.Tensor, grad_masks: torch.Tensor, img_hw, use_cropped_mask: bool = True):
+    """Gradients of assemble_loss_masks w.r.t. proto and pos_coef given dL/dmasks (what TensorFlow's autodiff
+    derives from ``loss/loss_yolact.py:239-253``): returns (grad_proto [B,ph,pw,32], grad_coef [B,rows,32]).
+    ``masks`` must be assemble_loss_masks' output for the same inputs.  Deterministic (fixed summation order)."""
+    B, ph, pw, K = proto.shape
+    rows = pos_coef.shape[1]
+    dev = proto.device
+    for name, t, shape, dt in (("proto", proto, (B, ph, pw, 32), torch.float32), ("pos_coef", pos_coef, (B, rows, 32), torch.float32),
+                               ("pos_prior_box", pos_prior_box, (B, rows, 4), torch.float32), ("num_pos", num_pos, (B,), torch.int32),
+                               ("masks", masks, (B, rows, ph, pw), torch.float32), ("grad_masks", grad_masks, (B, rows, ph, pw), torch.float32)):
+        if not t.is_cuda or t.device != dev or t.dtype != dt or tuple(t.shape) != shape or not t.is_contiguous():
+            raise ValueError(f"{name} must be a contiguous {dt} CUDA tensor of shape {shape}")
+    grad_proto = torch.empty((B, ph, pw, 32), dtype=torch.float32, device=dev)
+    grad_coef = torch.empty((B, rows, 32), dtype=torch.float32, device=dev)
+    ws = torch.empty((B, rows, 4), dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    _lib.check(_lib.load().yp_assemble_masks_backward(dev.index, B, rows, ph, pw, int(img_hw[0]), int(img_hw[1]), int(use_cropped_mask),
+                                                      proto.data_ptr(), pos_coef.data_ptr(), pos_prior_box.data_ptr(), num_pos.data_ptr(),
+                                                      masks.data_ptr(), grad_masks.data_ptr(), ws.data_ptr(), grad_proto.data_ptr(),
+                                                      grad_coef.data_ptr(), ctypes.c_void_p(stream)))
+    return grad_proto, grad_coef
+
+
+class LossMaskAssembly(torch.autograd.Function):
+    """Differentiable mask assembly of the training loss: ``LossMaskAssembly.apply(proto, pos_coef, pos_prior_box,
+    num_pos, img_h, img_w, use_cropped_mask)`` -> masks [B,rows,ph,pw]; gradients flow to proto and pos_coef
+    (the boxes are constants of the crop, as in the reference: utils.crop multiplies by a 0/1 mask)."""
+
+    @staticmethod
+    def forward(ctx, proto, pos_coef, pos_prior_box, num_pos, img_h, img_w, use_cropped_mask=True):
+        proto, pos_coef, pos_prior_box = proto.contiguous(), pos_coef.contiguous(), pos_prior_box.contiguous()
+        masks = assemble_loss_masks(proto, pos_coef, pos_prior_box, num_pos, (img_h, img_w), use_cropped_mask)
+        ctx.save_for_backward(proto, pos_coef, pos_prior_box, num_pos, masks)
+        ctx.cfg = (int(img_h), int(img_w), bool(use_cropped_mask))
+        return masks
+
+    @staticmethod
+    def backward(ctx, grad_masks):
+        proto, pos_coef, pos_prior_box, num_pos, masks = ctx.saved_tensors
+        gp, gc = assemble_loss_masks_backward(proto, pos_coef, pos_prior_box, num_pos, masks, grad_masks.contiguous(),
+                                              ctx.cfg[:2], ctx.cfg[2])
+        return gp, gc, None, None, None, None, None

@@ -223,3 +223,8 @@ int yp_rle_limits(int* max_src_h, int* max_out_h);
 hipError_t yp_launch_loss_masks(int batch, int rows, int ph, int pw, int img_h, int img_w, int use_crop, const float* proto,
                                 const float* coef, const float* boxes, const int32_t* num_rows, float* crop_ws, float* out_masks,
                                 hipStream_t st);
+hipError_t yp_launch_crop_edges(int total, int ph, int pw, int img_h, int img_w, int use_crop, const float* boxes, float* crop_ws,
+                                hipStream_t st);
+hipError_t yp_launch_loss_grads(int batch, int rows, int ph, int pw, int img_h, int img_w, int use_crop, const float* proto,
+                                const float* coef, const float* boxes, const int32_t* num_rows, const float* masks,
+                                const float* grad_masks, float* crop_ws, float* grad_proto, float* grad_coef, hipStream_t st);

@@ -280,12 +280,18 @@ __global__ __launch_bounds__(256) void crop_edges_kernel(const float4* boxes /* 
   crop[i] = cb;
 }
 
+hipError_t yp_launch_crop_edges(int total, int ph, int pw, int img_h, int img_w, int use_crop, const float* boxes, float* crop_ws,
+                                hipStream_t st) {
+  hipLaunchKernelGGL(crop_edges_kernel, dim3((total + 255) / 256), dim3(256), 0, st, reinterpret_cast<const float4*>(boxes),
+                     reinterpret_cast<float4*>(crop_ws), total, (float)img_h, (float)img_w, (float)ph, (float)pw, use_crop);
+  return hipGetLastError();
+}
+
 hipError_t yp_launch_loss_masks(int batch, int rows, int ph, int pw, int img_h, int img_w, int use_crop, const float* proto,
                                 const float* coef, const float* boxes, const int32_t* num_rows, float* crop_ws, float* out_masks,
                                 hipStream_t st) {
-  const int total = batch * rows;
-  hipLaunchKernelGGL(crop_edges_kernel, dim3((total + 255) / 256), dim3(256), 0, st, reinterpret_cast<const float4*>(boxes),
-                     reinterpret_cast<float4*>(crop_ws), total, (float)img_h, (float)img_w, (float)ph, (float)pw, use_crop);
+  const hipError_t e = yp_launch_crop_edges(batch * rows, ph, pw, img_h, img_w, use_crop, boxes, crop_ws, st);
+  if (e != hipSuccess) return e;
   MaskArgs a;
   a.proto = proto; a.coef = coef; a.crop = reinterpret_cast<const float4*>(crop_ws); a.num_det = num_rows;
   a.masks = out_masks; a.bitmaps = nullptr;
