@@ -202,14 +202,17 @@ int yp_assemble_masks(int32_t device_id, int32_t batch, int32_t rows, int32_t pr
  * output for the same proto / coef / boxes / num_rows (only the pixels inside a row's box are read).
  * Deterministic: fixed summation orders, no float atomics (csrc/loss_grad.hip states them;
  * oracle/detect_oracle.c restates them, and the GPU tests compare bit for bit).
- *   grad_proto [batch,ph,pw,32]   grad_coef [batch,rows,32]   crop_workspace [batch,rows,4] as above.
- * All device pointers; proto, coef, boxes, crop_workspace, grad_proto 16-byte aligned; asynchronous on
- * hip_stream; allocates nothing. */
+ *   grad_proto [batch,ph,pw,32]   grad_coef [batch,rows,32]
+ *   workspace: yp_assemble_masks_backward_workspace(batch, rows, proto_h) bytes of device memory the caller
+ *              provides (= 4*batch*rows*(4 + 32*proto_h): the crop edges and grad_coef per pixel row)
+ * All device pointers; proto, coef, boxes, workspace, grad_proto 16-byte aligned; proto_w <= 1024;
+ * asynchronous on hip_stream; allocates nothing. */
+int64_t yp_assemble_masks_backward_workspace(int32_t batch, int32_t rows, int32_t proto_h);
 int yp_assemble_masks_backward(int32_t device_id, int32_t batch, int32_t rows, int32_t proto_h, int32_t proto_w,
                                int32_t img_h, int32_t img_w, int32_t use_cropped_mask,
                                const float* proto, const float* coef, const float* boxes, const int32_t* num_rows,
                                const float* masks, const float* grad_masks,
-                               float* crop_workspace, float* grad_proto, float* grad_coef, void* hip_stream);
+                               float* workspace, float* grad_proto, float* grad_coef, void* hip_stream);
 
 /* pycocotools' compressed counts string (maskApi.c rleToString, what mask.encode puts in
  * rle['counts'], coco_eval.py:136-137) of n HOST counts.  Writes at most cap-1 characters and a

@@ -366,12 +366,10 @@ void yo_loss_masks(int num_pos, int K, int ph, int pw, int img_h, int img_w, int
  * forward returned it covers the crop too.  TF does not fix a summation order; the HIP kernels do, and
  * this restatement follows them so that the comparison can be bit-exact (YP-MATH, fp-contract off):
  *   grad_proto[p][k] = fmaf chain over r = 0..num_pos-1 (ascending) of dz[r][p] * pos_coef[r][k]
- *   grad_coef[r][k]  = YO_GC_STREAMS partial fmaf chains - stream s takes the pixel rows y with
- *                      y % YO_GC_STREAMS == s, in (y, x) ascending order, of dz[r][p] * proto[p][k] - added
- *                      up in stream order, starting from stream 0's value.
+ *   grad_coef[r][k]  = per pixel row y one fmaf chain over x ascending of dz[r][p] * proto[p][k]; the rows'
+ *                      values added up in ascending y, starting from +0.
  * Terms with dz == 0 change nothing (finite inputs), so the kernels skip the pixels outside the box.
  */
-#define YO_GC_STREAMS 16
 void yo_loss_masks_backward(int num_pos, int K, int ph, int pw, const float* proto, const float* pos_coef,
                             const float* masks, const float* grad_masks, float* grad_proto, float* grad_coef) {
   const size_t P = (size_t)ph * pw;
@@ -388,16 +386,15 @@ void yo_loss_masks_backward(int num_pos, int K, int ph, int pw, const float* pro
   for (int r = 0; r < num_pos; ++r)
     for (int k = 0; k < K; ++k) {
       float total = 0.0f;
-      for (int s = 0; s < YO_GC_STREAMS; ++s) {
+      for (int y = 0; y < ph; ++y) {
         float acc = 0.0f;
-        for (int y = s; y < ph; y += YO_GC_STREAMS)
-          for (int x = 0; x < pw; ++x) {
-            const size_t p = (size_t)y * pw + x;
-            const float m = masks[(size_t)r * P + p], g = grad_masks[(size_t)r * P + p];
-            const float dz = (g * m) * (1.0f - m);
-            acc = fmaf(dz, proto[p * K + k], acc);
-          }
-        total = s == 0 ? acc : total + acc;
+        for (int x = 0; x < pw; ++x) {
+          const size_t p = (size_t)y * pw + x;
+          const float m = masks[(size_t)r * P + p], g = grad_masks[(size_t)r * P + p];
+          const float dz = (g * m) * (1.0f - m);
+          acc = fmaf(dz, proto[p * K + k], acc);
+        }
+        total = total + acc;
       }
       grad_coef[(size_t)r * K + k] = total;
     }

@@ -150,9 +150,10 @@ def assemble_loss_masks_backward(proto: torch.Tensor, pos_coef: torch.Tensor, po
             raise ValueError(f"{name} must be a contiguous {dt} CUDA tensor of shape {shape}")
     grad_proto = torch.empty((B, ph, pw, 32), dtype=torch.float32, device=dev)
     grad_coef = torch.empty((B, rows, 32), dtype=torch.float32, device=dev)
-    ws = torch.empty((B, rows, 4), dtype=torch.float32, device=dev)
+    L = _lib.load()
+    ws = torch.empty((int(L.yp_assemble_masks_backward_workspace(B, rows, ph)) // 4,), dtype=torch.float32, device=dev)
     stream = torch.cuda.current_stream(dev).cuda_stream
-    _lib.check(_lib.load().yp_assemble_masks_backward(dev.index, B, rows, ph, pw, int(img_hw[0]), int(img_hw[1]), int(use_cropped_mask),
+    _lib.check(L.yp_assemble_masks_backward(dev.index, B, rows, ph, pw, int(img_hw[0]), int(img_hw[1]), int(use_cropped_mask),
                                                       proto.data_ptr(), pos_coef.data_ptr(), pos_prior_box.data_ptr(), num_pos.data_ptr(),
                                                       masks.data_ptr(), grad_masks.data_ptr(), ws.data_ptr(), grad_proto.data_ptr(),
                                                       grad_coef.data_ptr(), ctypes.c_void_p(stream)))

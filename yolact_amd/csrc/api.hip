@@ -454,28 +454,34 @@ extern "C" int yp_assemble_masks(int32_t device_id, int32_t batch, int32_t rows,
   return YP_OK;
 }
 
+extern "C" int64_t yp_assemble_masks_backward_workspace(int32_t batch, int32_t rows, int32_t proto_h) {
+  if (batch < 0 || rows < 1 || proto_h < 1) return fail(YP_EINVAL, "yp_assemble_masks_backward_workspace: bad argument");
+  return (int64_t)(yp_loss_grads_workspace_floats(batch, rows, proto_h) * sizeof(float));
+}
+
 extern "C" int yp_assemble_masks_backward(int32_t device_id, int32_t batch, int32_t rows, int32_t proto_h, int32_t proto_w,
                                           int32_t img_h, int32_t img_w, int32_t use_cropped_mask, const float* proto,
                                           const float* coef, const float* boxes, const int32_t* num_rows, const float* masks,
-                                          const float* grad_masks, float* crop_workspace, float* grad_proto, float* grad_coef,
+                                          const float* grad_masks, float* workspace, float* grad_proto, float* grad_coef,
                                           void* hip_stream) {
-  if (!proto || !coef || !boxes || !num_rows || !masks || !grad_masks || !crop_workspace || !grad_proto || !grad_coef)
+  if (!proto || !coef || !boxes || !num_rows || !masks || !grad_masks || !workspace || !grad_proto || !grad_coef)
     return fail(YP_EINVAL, "yp_assemble_masks_backward: null pointer");
   if (batch < 0 || rows < 1 || rows > YP_SORT_MAX) return fail(YP_EINVAL, "yp_assemble_masks_backward: rows must be in [1, %d]", YP_SORT_MAX);
   if (proto_h < 1 || proto_w < 1 || img_h < 1 || img_w < 1) return fail(YP_EINVAL, "yp_assemble_masks_backward: bad proto/image size");
+  if (proto_w > 1024) return fail(YP_EINVAL, "yp_assemble_masks_backward: proto_w %d exceeds 1024 (a prototype row must fit in LDS)", proto_w);
   const long long P = (long long)proto_h * proto_w;
   if (P > (1ll << 26)) return fail(YP_EINVAL, "yp_assemble_masks_backward: %lld pixels per prototype exceed 2^26", P);
-  if ((long long)batch * rows >= (1ll << 31) || (long long)batch * ((P + 255) / 256) >= (1ll << 31))
+  if ((long long)batch * rows >= (1ll << 31) || (long long)batch * ((P + 255) / 256) >= (1ll << 31) || (long long)batch * proto_h >= (1ll << 31))
     return fail(YP_EINVAL, "yp_assemble_masks_backward: batch too large");
-  if ((((uintptr_t)proto | (uintptr_t)coef | (uintptr_t)boxes | (uintptr_t)crop_workspace | (uintptr_t)grad_proto) & 15u) != 0)
-    return fail(YP_EINVAL, "yp_assemble_masks_backward: proto, coef, boxes, crop_workspace and grad_proto must be 16-byte aligned");
+  if ((((uintptr_t)proto | (uintptr_t)coef | (uintptr_t)boxes | (uintptr_t)workspace | (uintptr_t)grad_proto) & 15u) != 0)
+    return fail(YP_EINVAL, "yp_assemble_masks_backward: proto, coef, boxes, workspace and grad_proto must be 16-byte aligned");
   if (batch == 0) return YP_OK;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(YP_ENODEV, "no HIP device available");
   if (device_id < 0 || device_id >= ndev) return fail(YP_ENODEV, "device_id %d out of range (%d devices)", device_id, ndev);
   YP_ON_DEVICE(device_id);
   YP_HIP(yp_launch_loss_grads(batch, rows, proto_h, proto_w, img_h, img_w, use_cropped_mask, proto, coef, boxes, num_rows, masks,
-                              grad_masks, crop_workspace, grad_proto, grad_coef, (hipStream_t)hip_stream));
+                              grad_masks, workspace, grad_proto, grad_coef, (hipStream_t)hip_stream));
   return YP_OK;
 }
 

@@ -225,6 +225,7 @@ hipError_t yp_launch_loss_masks(int batch, int rows, int ph, int pw, int img_h, 
                                 hipStream_t st);
 hipError_t yp_launch_crop_edges(int total, int ph, int pw, int img_h, int img_w, int use_crop, const float* boxes, float* crop_ws,
                                 hipStream_t st);
+size_t yp_loss_grads_workspace_floats(int batch, int rows, int ph);
 hipError_t yp_launch_loss_grads(int batch, int rows, int ph, int pw, int img_h, int img_w, int use_crop, const float* proto,
                                 const float* coef, const float* boxes, const int32_t* num_rows, const float* masks,
-                                const float* grad_masks, float* crop_ws, float* grad_proto, float* grad_coef, hipStream_t st);
+                                const float* grad_masks, float* workspace, float* grad_proto, float* grad_coef, hipStream_t st);

@@ -8,19 +8,22 @@
 // TF fixes no summation order.  These kernels do - the tests' C restatement follows the same one, so
 // that the comparison is bit-exact - and a result is reproducible run to run (no float atomics):
 //   grad_proto: one fma chain over n ascending;
-//   grad_coef:  YP_GC_STREAMS fma chains, stream s over the pixel rows y % YP_GC_STREAMS == s in (y, x)
-//               order, added up in stream order.
+//   grad_coef:  per pixel row y one fma chain over x ascending; the rows' values added up in ascending y,
+//               starting from +0.
 // A term with dz == 0 leaves a chain as it is (finite inputs), so only pixels inside a row's crop box
 // are read: per image ~10 % of the 2 x rows x P mask and gradient values.
 //
-// Both kernels are bound by cache traffic and latency, not by HBM or the FMA rate: grad_proto reads
-// the masks and gradients inside the boxes once and writes 4PK bytes per image; grad_coef re-reads
-// the image's prototypes (4PK bytes, L2 / Infinity Cache) for every row's box.
+// grad_proto: a lane owns a pixel (32 accumulators), visits the rows whose box can touch its wave's 64
+// pixels, reads mask and gradient inside the boxes once and writes 4PK bytes per image.
+// grad_coef: a workgroup owns one pixel row of one image: the row's prototypes go to LDS once and serve
+// every detection whose box covers the row (first version: one workgroup per detection re-read the
+// image's prototypes from L2 / Infinity Cache for every box - 1.2 GB per call at 13 % box coverage,
+// 173 us); the per-row values go to the workspace and a second kernel adds them up in row order.
 #include "common.hpp"
 
-#define YP_GC_STREAMS 16
-#define YP_GC_THREADS (YP_GC_STREAMS * YP_MASK_DIM)
 #define YP_LG_BLOCK 256
+#define YP_GC_THREADS 256                        // grad_coef: 8 half-waves, each one detection at a time
+#define YP_GC_HALVES (YP_GC_THREADS / YP_MASK_DIM)
 
 struct LossGradArgs {
   const float* proto;        // [B,P,32]
@@ -31,6 +34,7 @@ struct LossGradArgs {
   const float* grad;         // [B,rows,P] dL/dmasks
   float* gproto;             // [B,P,32]
   float* gcoef;              // [B,rows,32]
+  float* part;               // [B,rows,ph,32] grad_coef per pixel row (written where a box covers the row)
   int rows, P, pw, ph;
 };
 
@@ -52,15 +56,27 @@ __global__ __launch_bounds__(YP_LG_BLOCK) void loss_grad_proto_kernel(const Loss
   float acc[YP_MASK_DIM];
 #pragma unroll
   for (int k = 0; k < YP_MASK_DIM; ++k) acc[k] = 0.0f;
-  for (int n = 0; n < N; ++n) {
-    const float4 cb = crop[n];
-    const bool in = live && (fcol >= cb.x) && (fcol < cb.y) && (frow >= cb.z) && (frow < cb.w);   // utils/utils.py:119-126
-    if (__ballot(in) == 0) continue;   // wave-uniform
-    float dz = 0.0f;
-    if (in) dz = dz_of(gr[(size_t)n * a.P], mk[(size_t)n * a.P]);
-    const float* cf = coef + (size_t)n * YP_MASK_DIM;   // wave-uniform address
+  // the wave's 64 consecutive pixels lie in rows ra..rb; over one row, columns ca..cb2, else all of them
+  const int lane = (int)threadIdx.x & 63;
+  const int pfirst = min(p - lane, a.P - 1), plast = min(p - lane + 63, a.P - 1);
+  const int ra = pfirst / a.pw, rb = plast / a.pw;
+  const float fra = (float)ra, frb = (float)rb;
+  const float fca = ra == rb ? (float)(pfirst - ra * a.pw) : 0.0f, fcb = ra == rb ? (float)(plast - rb * a.pw) : (float)(a.pw - 1);
+  for (int n0 = 0; n0 < N; n0 += 64) {
+    const float4 ce = crop[min(n0 + lane, N - 1)];
+    const bool touch = (n0 + lane < N) && (fcb >= ce.x) && (fca < ce.y) && (frb >= ce.z) && (fra < ce.w);
+    unsigned long long rel = __ballot(touch);
+    while (rel) {                      // wave-uniform: ascending n, as the chain's order demands
+      const int n = n0 + __builtin_ctzll(rel);
+      rel &= rel - 1ull;
+      const float4 cb = crop[n];
+      const bool in = live && (fcol >= cb.x) && (fcol < cb.y) && (frow >= cb.z) && (frow < cb.w);   // utils/utils.py:119-126
+      float dz = 0.0f;
+      if (in) dz = dz_of(gr[(size_t)n * a.P], mk[(size_t)n * a.P]);
+      const float* cf = coef + (size_t)n * YP_MASK_DIM;   // wave-uniform address
 #pragma unroll
-    for (int k = 0; k < YP_MASK_DIM; ++k) acc[k] = __builtin_fmaf(dz, cf[k], acc[k]);
+      for (int k = 0; k < YP_MASK_DIM; ++k) acc[k] = __builtin_fmaf(dz, cf[k], acc[k]);
+    }
   }
   if (live) {
     float4* out = reinterpret_cast<float4*>(a.gproto + ((size_t)b * a.P + p) * YP_MASK_DIM);
@@ -69,62 +85,113 @@ __global__ __launch_bounds__(YP_LG_BLOCK) void loss_grad_proto_kernel(const Loss
   }
 }
 
-// grad_coef: one workgroup per (image, row); 32 lanes (one per coefficient) form a stream.
-__global__ __launch_bounds__(YP_GC_THREADS) void loss_grad_coef_kernel(const LossGradArgs a) {
-  __shared__ float part[YP_GC_STREAMS][YP_MASK_DIM];
-  const int b = (int)blockIdx.x / a.rows, n = (int)blockIdx.x - b * a.rows;
-  const int t = (int)threadIdx.x, k = t & (YP_MASK_DIM - 1), s = t / YP_MASK_DIM;
-  float* const out = a.gcoef + ((size_t)b * a.rows + n) * YP_MASK_DIM;
-  if (n >= a.num_rows[b]) {   // workgroup-uniform
-    if (t < YP_MASK_DIM) out[t] = 0.0f;
-    return;
+// The integer superset of a crop box's pixels that both grad_coef kernels use (pixels outside the box have
+// m == 0 and add nothing; NaN edges compare false everywhere in the forward pass, so any range is right).
+__device__ __forceinline__ void box_range(const float4 cb, int pw, int ph, int& x0, int& x1, int& y0, int& y1) {
+  x0 = (int)fminf(fmaxf(floorf(cb.x), 0.0f), (float)pw); x1 = (int)fminf(fmaxf(ceilf(cb.y), 0.0f), (float)pw);
+  y0 = (int)fminf(fmaxf(floorf(cb.z), 0.0f), (float)ph); y1 = (int)fminf(fmaxf(ceilf(cb.w), 0.0f), (float)ph);
+}
+
+// grad_coef, step 1: workgroup (b, y) - the prototypes of pixel row y in LDS; a half-wave (lane = coefficient
+// k) takes one detection whose box covers the row at a time: dz of the row's pixels into LDS (x-parallel),
+// then the chain over x.  Dynamic LDS: prow[pw][32] | dzs[YP_GC_HALVES][pwp] | rel[256] ints.
+__global__ __launch_bounds__(YP_GC_THREADS) void loss_grad_coef_rows_kernel(const LossGradArgs a, int pwp) {
+  extern __shared__ __align__(16) float lg_lds[];
+  float* const prow = lg_lds;
+  float* const dzs = prow + (size_t)a.pw * YP_MASK_DIM;
+  int* const rel = reinterpret_cast<int*>(dzs + YP_GC_HALVES * pwp);
+  __shared__ int nrel;
+  const int b = (int)blockIdx.x / a.ph, y = (int)blockIdx.x - b * a.ph;
+  const int t = (int)threadIdx.x, k = t & (YP_MASK_DIM - 1), h = t / YP_MASK_DIM;
+  const int N = min(a.num_rows[b], a.rows);
+  if (t == 0) nrel = 0;
+  {
+    const float4* src = reinterpret_cast<const float4*>(a.proto + ((size_t)b * a.P + (size_t)y * a.pw) * YP_MASK_DIM);
+    float4* dst = reinterpret_cast<float4*>(prow);
+    for (int i = t; i < a.pw * (YP_MASK_DIM / 4); i += YP_GC_THREADS) dst[i] = src[i];
   }
-  const float4 cb = a.crop[(size_t)b * a.rows + n];
-  // an integer superset of the box (pixels outside it have m == 0 and add nothing); NaN edges compare
-  // false everywhere in the forward pass, so any range is right for them
-  const int x0 = (int)fminf(fmaxf(floorf(cb.x), 0.0f), (float)a.pw), x1 = (int)fminf(fmaxf(ceilf(cb.y), 0.0f), (float)a.pw);
-  const int y0 = (int)fminf(fmaxf(floorf(cb.z), 0.0f), (float)a.ph), y1 = (int)fminf(fmaxf(ceilf(cb.w), 0.0f), (float)a.ph);
-  const float* const mk = a.masks + ((size_t)b * a.rows + n) * a.P;
-  const float* const gr = a.grad + ((size_t)b * a.rows + n) * a.P;
-  const float* const pr = a.proto + (size_t)b * a.P * YP_MASK_DIM + k;
-  float acc = 0.0f;
-  for (int y = y0 + ((s - y0) % YP_GC_STREAMS + YP_GC_STREAMS) % YP_GC_STREAMS; y < y1; y += YP_GC_STREAMS) {
-    const int base = y * a.pw;
-    int x = x0;
-    for (; x + 8 <= x1; x += 8) {          // eight pixels' loads in flight, the chain in order
-      float m[8], g[8], pv[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        m[u] = mk[base + x + u];
-        g[u] = gr[base + x + u];
-        pv[u] = pr[(size_t)(base + x + u) * YP_MASK_DIM];
-      }
-#pragma unroll
-      for (int u = 0; u < 8; ++u) acc = __builtin_fmaf(dz_of(g[u], m[u]), pv[u], acc);
-    }
-    for (; x < x1; ++x) acc = __builtin_fmaf(dz_of(gr[base + x], mk[base + x]), pr[(size_t)(base + x) * YP_MASK_DIM], acc);
-  }
-  part[s][k] = acc;
   __syncthreads();
-  if (t < YP_MASK_DIM) {
-    float total = part[0][t];
+  for (int n = t; n < N; n += YP_GC_THREADS) {   // (rows <= 256: one trip; the list's order does not matter)
+    int x0, x1, y0, y1;
+    box_range(a.crop[(size_t)b * a.rows + n], a.pw, a.ph, x0, x1, y0, y1);
+    if (y >= y0 && y < y1 && x0 < x1) rel[atomicAdd(&nrel, 1)] = n;
+  }
+  __syncthreads();
+  const int nr = nrel;
+  float* const dzh = dzs + h * pwp;
+  for (int i = h; i < nr; i += YP_GC_HALVES) {   // (uniform per half-wave; the two halves of a wave may differ)
+    const int n = rel[i];
+    int x0, x1, y0, y1;
+    box_range(a.crop[(size_t)b * a.rows + n], a.pw, a.ph, x0, x1, y0, y1);
+    const float* const mk = a.masks + ((size_t)b * a.rows + n) * a.P + (size_t)y * a.pw;
+    const float* const gr = a.grad + ((size_t)b * a.rows + n) * a.P + (size_t)y * a.pw;
+    for (int x = x0 + k; x < x1; x += YP_MASK_DIM) dzh[x - x0] = dz_of(gr[x], mk[x]);
+    __builtin_amdgcn_wave_barrier();           // the half-wave's LDS stores precede its loads (one wave: in order)
+    float acc = 0.0f;
+    const int w = x1 - x0;
+    int j = 0;
+    for (; j + 8 <= w; j += 8) {
+      float dz[8], pv[8];
 #pragma unroll
-    for (int q = 1; q < YP_GC_STREAMS; ++q) total = total + part[q][t];
-    out[t] = total;
+      for (int u = 0; u < 8; ++u) { dz[u] = dzh[j + u]; pv[u] = prow[(x0 + j + u) * YP_MASK_DIM + k]; }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc = __builtin_fmaf(dz[u], pv[u], acc);
+    }
+    for (; j < w; ++j) acc = __builtin_fmaf(dzh[j], prow[(x0 + j) * YP_MASK_DIM + k], acc);
+    a.part[(((size_t)b * a.rows + n) * a.ph + y) * YP_MASK_DIM + k] = acc;
+    __builtin_amdgcn_wave_barrier();           // dzh is rewritten by the next detection
   }
 }
 
+// grad_coef, step 2: the rows' values of a detection added up in ascending y, from +0 (a half-wave per detection).
+__global__ __launch_bounds__(YP_GC_THREADS) void loss_grad_coef_sum_kernel(const LossGradArgs a, int total) {
+  const int t = (int)threadIdx.x, k = t & (YP_MASK_DIM - 1), h = t / YP_MASK_DIM;
+  const int i = (int)blockIdx.x * YP_GC_HALVES + h;   // b * rows + n
+  if (i >= total) return;
+  const int b = i / a.rows, n = i - b * a.rows;
+  float tot = 0.0f;
+  if (n < a.num_rows[b]) {
+    int x0, x1, y0, y1;
+    box_range(a.crop[i], a.pw, a.ph, x0, x1, y0, y1);
+    if (x0 < x1) {
+      const float* pt = a.part + (size_t)i * a.ph * YP_MASK_DIM + k;
+      int y = y0;
+      for (; y + 8 <= y1; y += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = pt[(size_t)(y + u) * YP_MASK_DIM];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) tot = tot + v[u];
+      }
+      for (; y < y1; ++y) tot = tot + pt[(size_t)y * YP_MASK_DIM];
+    }
+  }
+  a.gcoef[(size_t)i * YP_MASK_DIM + k] = tot;
+}
+
+size_t yp_loss_grads_workspace_floats(int batch, int rows, int ph) { return (size_t)batch * rows * (4 + (size_t)ph * YP_MASK_DIM); }
+
 hipError_t yp_launch_loss_grads(int batch, int rows, int ph, int pw, int img_h, int img_w, int use_crop, const float* proto,
                                 const float* coef, const float* boxes, const int32_t* num_rows, const float* masks,
-                                const float* grad_masks, float* crop_ws, float* grad_proto, float* grad_coef, hipStream_t st) {
+                                const float* grad_masks, float* workspace, float* grad_proto, float* grad_coef, hipStream_t st) {
+  float* const crop_ws = workspace;                        // [B,rows,4]
+  float* const part = workspace + (size_t)batch * rows * 4;   // [B,rows,ph,32]
   hipError_t e = yp_launch_crop_edges(batch * rows, ph, pw, img_h, img_w, use_crop, boxes, crop_ws, st);
   if (e != hipSuccess) return e;
   LossGradArgs a;
   a.proto = proto; a.coef = coef; a.crop = reinterpret_cast<const float4*>(crop_ws); a.num_rows = num_rows;
-  a.masks = masks; a.grad = grad_masks; a.gproto = grad_proto; a.gcoef = grad_coef;
+  a.masks = masks; a.grad = grad_masks; a.gproto = grad_proto; a.gcoef = grad_coef; a.part = part;
   a.rows = rows; a.P = ph * pw; a.pw = pw; a.ph = ph;
   const int bpi = (a.P + YP_LG_BLOCK - 1) / YP_LG_BLOCK;
   hipLaunchKernelGGL(loss_grad_proto_kernel, dim3(batch * bpi), dim3(YP_LG_BLOCK), 0, st, a, bpi);
-  hipLaunchKernelGGL(loss_grad_coef_kernel, dim3(batch * rows), dim3(YP_GC_THREADS), 0, st, a);
+  const int pwp = (pw + 3) / 4 * 4;
+  const size_t lds = ((size_t)pw * YP_MASK_DIM + (size_t)YP_GC_HALVES * pwp) * sizeof(float) + 256 * sizeof(int);
+  if (lds > 48 * 1024) {   // (proto rows wider than ~350 pixels)
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&loss_grad_coef_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(loss_grad_coef_rows_kernel, dim3(batch * ph), dim3(YP_GC_THREADS), lds, st, a, pwp);
+  const int total = batch * rows;
+  hipLaunchKernelGGL(loss_grad_coef_sum_kernel, dim3((total + YP_GC_HALVES - 1) / YP_GC_HALVES), dim3(YP_GC_THREADS), 0, st, a, total);
   return hipGetLastError();
 }
