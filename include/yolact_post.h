@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define YP_VERSION 200 /* 0.2.0 */
+#define YP_VERSION 210 /* 0.2.1 */
 
 enum {
   YP_OK = 0,
