@@ -91,6 +91,24 @@ def test_out_height_around_the_64_row_chunks():
         _check(masks, [3], (oh, 33), "resize_then_threshold")
 
 
+@pytest.mark.parametrize("order", ["resize_then_threshold", "threshold_then_resize"])
+@pytest.mark.parametrize("threshold", [0.0, 0.5, -0.25])
+def test_zero_skipping_does_not_change_the_encoding(order, threshold):
+    """The kernel skips columns and 64-row chunks whose source taps are all zero (threshold >= 0; a negative
+    threshold sets every such pixel and takes the plain path): all-zero masks, single pixels in the corners
+    and in the middle, box-limited blobs, negative values and -0.0 outside the box, at a size with several
+    column batches and row chunks."""
+    rng = np.random.default_rng(15)
+    h, w, oh, ow = 37, 41, 200, 150
+    masks = np.zeros((1, 8, h, w), np.float32)
+    masks[0, 1, 0, 0] = 0.9; masks[0, 2, h - 1, w - 1] = 0.9; masks[0, 3, h // 2, w // 2] = 0.7
+    masks[0, 4] = _blobs(rng, 1, 1, h, w)[0, 0]
+    masks[0, 5] = -np.abs(_blobs(rng, 1, 1, h, w)[0, 0])            # negative inside the box, -0.0 / 0.0 outside
+    masks[0, 6, 5:9, :] = rng.random((4, w)); masks[0, 6, 30:33, 10:12] = 1.0
+    masks[0, 7, :, 20] = rng.random(h)
+    _check(masks, [8], (oh, ow), order, threshold=threshold)
+
+
 def test_counts_capacity_overflow_is_reported_and_retried():
     import torch
     from yolact_amd import _lib

@@ -95,6 +95,14 @@ def main():
     bwd_big = timed(lambda: consumer.assemble_loss_masks_backward(proto, coef, big, full, masks_big, grad, (cfg.img_h, cfg.img_w)))
     res["loss_mask_assembly_large_boxes"] = {"forward_ms": round(fwd_big, 4), "backward_ms": round(bwd_big, 4), "rows": B * cfg.max_dets,
                                              "fraction_of_pixels_inside_boxes": round(float((masks_big != 0).float().mean()), 4)}
+    # F2 again on those masks: boxes of a realistic size instead of the synthetic detections' small ones
+    r = consumer.masks_to_rle(masks_big, full, (cfg.img_h, cfg.img_w), rle_cap=20000)
+    cap_big = int(r["counts"].shape[2])
+    rle_big = timed(lambda: consumer.masks_to_rle(masks_big, full, (cfg.img_h, cfg.img_w), rle_cap=cap_big))
+    res["resize_then_threshold_large_boxes"] = {"ms_per_batch": round(rle_big, 4), "detections": B * cfg.max_dets,
+                                                "detections_per_s": round(B * cfg.max_dets / rle_big * 1e3, 1),
+                                                "fraction_of_pixels_inside_boxes": round(float((masks_big != 0).float().mean()), 4),
+                                                "max_runs": int(r["len"].max())}
     res["loss_mask_assembly"] = {"forward_ms": round(fwd_ms, 4), "backward_ms": round(bwd_ms, 4), "rows": int(npos.sum()),
                                  "fraction_of_pixels_inside_boxes": round(inside, 4),
                                  "torch_rocblas_forward_plus_backward_ms": round(ref_ms, 4),

@@ -23,6 +23,8 @@
 //      number of boundaries before it and the position of the last one, and the cell writes its run
 //      lengths straight to their final places: count j = position of boundary j minus position of
 //      boundary j-1.  No second pass, no atomics.
+// Columns whose source columns are all zero, and 64-row chunks whose rows of the row buffer are all zero,
+// are not computed (Detect's masks are zero outside their crop box; see "Zero skipping" below).
 // HBM traffic is the source mask (once) plus the counts (and the optional bitmap): the kernel is
 // bound by instruction issue.
 #include "common.hpp"
@@ -93,7 +95,10 @@ __global__ __launch_bounds__(YP_RLE_THREADS) void mask_rle_kernel(const RleArgs 
   int* const s_wsum = reinterpret_cast<int*>(lp_);                    lp_ += YP_RLE_WAVES * 4;
   int* const s_wmax = reinterpret_cast<int*>(lp_);                    lp_ += YP_RLE_WAVES * 4;
   float* const s_fy = reinterpret_cast<float*>(lp_);                  lp_ += (size_t)p.out_h * 4;
-  short* const s_sy = reinterpret_cast<short*>(lp_);
+  short* const s_sy = reinterpret_cast<short*>(lp_);                  lp_ += (size_t)((p.out_h * 2 + 15) & ~15);
+  int* const s_clo = reinterpret_cast<int*>(lp_);                     lp_ += 64 * 4;   // first / last source row a 64-row chunk reads
+  int* const s_chi = reinterpret_cast<int*>(lp_);                     lp_ += 64 * 4;
+  int* const s_colnz = reinterpret_cast<int*>(lp_);                   // [ws] 1 = the staged source column holds a non-zero value
   int* const s_hcol_i = reinterpret_cast<int*>(s_hcol);
 
   const float* __restrict__ S = p.masks + slot * (size_t)p.ph * p.pw;
@@ -114,6 +119,18 @@ __global__ __launch_bounds__(YP_RLE_THREADS) void mask_rle_kernel(const RleArgs 
     s_sy[y] = (short)s;
   }
   __syncthreads();
+  // Zero skipping.  Detect's masks are zero outside their crop box, and a resized pixel whose source taps are
+  // all zero is zero: 0 > threshold is false for any threshold >= 0, in both threshold orders.  So a column
+  // whose two source columns are all zero, and a 64-row chunk whose source rows of the row buffer are all
+  // zero, have no set bits and are not computed.  (cv::resize's copy for equal sizes and negative
+  // thresholds take the plain path.)
+  const bool skip_ok = !identity && p.threshold >= 0.0f;
+  if (t < HB) {
+    s_clo[t] = min(max((int)s_sy[t * 64], 0), phm1);
+    s_chi[t] = min(max((int)s_sy[min(t * 64 + 63, p.out_h - 1)] + 1, 0), phm1);
+  }
+  const u64 all_chunks = HB >= 64 ? ~0ull : ((1ull << HB) - 1ull);
+  __syncthreads();
 
   const int cpw = p.ncols / YP_RLE_WAVES;        // columns per wave and batch
   int total = 0;              // boundaries before the current batch (identical in every thread)
@@ -127,9 +144,15 @@ __global__ __launch_bounds__(YP_RLE_THREADS) void mask_rle_kernel(const RleArgs 
       float f_; bool r_;
       linear_coeff_x(x0, p.scale_x, p.pw, sx_lo, f_, r_);
       const int wcols = min(p.ws, p.pw - sx_lo);
+      if (skip_ok) {
+        if (t < p.ws) s_colnz[t] = 0;
+        __syncthreads();
+      }
       for (int idx = t; idx < p.ph * wcols; idx += YP_RLE_THREADS) {
         const int r = idx / wcols, c = idx - r * wcols;
-        s_src[r * p.ws + c] = S[(size_t)r * p.pw + sx_lo + c];
+        const float v = S[(size_t)r * p.pw + sx_lo + c];
+        s_src[r * p.ws + c] = v;
+        if (skip_ok && v != 0.0f) s_colnz[c] = 1;     // (every writer stores the same value)
       }
       __syncthreads();
     }
@@ -138,23 +161,40 @@ __global__ __launch_bounds__(YP_RLE_THREADS) void mask_rle_kernel(const RleArgs 
       if (col >= nc) break;
       const int x = x0 + col;
       // ---- A: horizontal pass for this column ------------------------------------------------------
+      int rmin = 0x7fffffff, rmax = -1;          // rows of the row buffer that are not zero (wave-uniform)
       if (!identity) {
         int sx; float fx; bool right;
         linear_coeff_x(x, p.scale_x, p.pw, sx, fx, right);
         const float a0 = one - fx, a1 = fx;
         const int ia0 = (int)rintf(a0 * cscale), ia1 = (int)rintf(a1 * cscale);   // saturate_cast<short>: cvRound
         const int sx1 = min(sx + 1, p.pw - 1);
+        if (skip_ok && p.ws > 0 && s_colnz[sx - sx_lo] == 0 && s_colnz[sx1 - sx_lo] == 0) {   // wave-uniform
+          if (lane < HB) s_bits[col * HB + lane] = 0ull;
+          continue;
+        }
         for (int r = lane; r < p.ph; r += YP_WAVE) {
           float s0, s1;
           if (p.ws > 0) { s0 = s_src[r * p.ws + (sx - sx_lo)]; s1 = s_src[r * p.ws + (sx1 - sx_lo)]; }
           else { s0 = S[(size_t)r * p.pw + sx]; s1 = S[(size_t)r * p.pw + sx1]; }
+          bool nz;
           if (!fixed) {
-            s_hcol[r] = right ? s0 * one : s0 * a0 + s1 * a1;
+            const float hv = right ? s0 * one : s0 * a0 + s1 * a1;
+            s_hcol[r] = hv;
+            nz = hv != 0.0f;
           } else {
             const int b0 = s0 > p.threshold ? 1 : 0, b1 = s1 > p.threshold ? 1 : 0;            // train.py:497
-            s_hcol_i[r] = right ? b0 * 2048 : b0 * ia0 + b1 * ia1;
+            const int hv = right ? b0 * 2048 : b0 * ia0 + b1 * ia1;
+            s_hcol_i[r] = hv;
+            nz = hv != 0;
+          }
+          const u64 nzm = __ballot(nz);          // (the lanes of this trip: rows r - lane .. r - lane + 63)
+          if (nzm) {
+            rmin = min(rmin, r - lane + (int)__builtin_ctzll(nzm));
+            rmax = r - lane + 63 - (int)__builtin_clzll(nzm);
           }
         }
+        rmin = __builtin_amdgcn_readfirstlane(rmin);
+        rmax = __builtin_amdgcn_readfirstlane(rmax);
         __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0): single wave, LDS in order
         __builtin_amdgcn_wave_barrier();
       }
@@ -180,7 +220,11 @@ __global__ __launch_bounds__(YP_RLE_THREADS) void mask_rle_kernel(const RleArgs 
         const u64 m = __ballot(bit);
         mym = lane == c ? m : mym;
       };
-      for (int c = 0; c < HB; ++c) {
+      u64 todo = all_chunks;
+      if (skip_ok) todo = __ballot(lane < HB && s_chi[lane] >= rmin && s_clo[lane] <= rmax);
+      while (todo) {                             // wave-uniform
+        const int c = (int)__builtin_ctzll(todo);
+        todo &= todo - 1ull;
         const int y = min(c * 64 + lane, p.out_h - 1);
         const int s = s_sy[y];
         const float f = s_fy[y];
@@ -278,7 +322,7 @@ hipError_t yp_launch_mask_rle(int batch, int max_dets, int ph, int pw, const flo
     attr_set = true;
   }
   const size_t lds = (size_t)((ph * a.ws * 4 + 15) & ~15) + (size_t)((YP_RLE_WAVES * ph * 4 + 15) & ~15) + YP_RLE_CELLS * 8 +
-                     2 * YP_RLE_WAVES * 4 + (size_t)out_h * 6 + 16;
+                     2 * YP_RLE_WAVES * 4 + (size_t)out_h * 4 + (size_t)((out_h * 2 + 15) & ~15) + 2 * 64 * 4 + (size_t)(a.ws + 4) * 4 + 16;
   hipLaunchKernelGGL(mask_rle_kernel, dim3(max_dets, batch), dim3(YP_RLE_THREADS), lds, st, a);
   return hipGetLastError();
 }
