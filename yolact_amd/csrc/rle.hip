@@ -8,7 +8,7 @@
 // pass first, plain float multiplies and adds / 11-bit fixed point for bytes); the run lengths are the
 // column-major counts of coco_eval.py:91-98 (binary_mask_to_rle) = pycocotools' rleEncode.
 //
-// One 1024-thread workgroup per detection walks the output image in column-major order, a batch of
+// One workgroup per detection (512 threads, 1024 for outputs taller than 1024 rows) walks the output image in column-major order, a batch of
 // up to 64 columns at a time, every wave taking consecutive columns of the batch:
 //   S  the source columns the batch needs (a [mask_h][~nc*scale+2] sub-block) are staged in LDS once,
 //      by all threads: one global round trip per batch instead of one per column;
@@ -29,10 +29,7 @@
 // bound by instruction issue.
 #include "common.hpp"
 
-#define YP_RLE_THREADS 1024
-#define YP_RLE_WAVES (YP_RLE_THREADS / YP_WAVE)
 #define YP_RLE_MAX_COLS 64        // columns per batch (one lane per column in phase C)
-#define YP_RLE_CELLS 1024         // 64-row chunks of bitmap a batch holds in LDS: ncols * ceil(out_h/64) <= this
 #define YP_RLE_MAX_SRC_H 512
 #define YP_RLE_MAX_OUT_H 4096
 #define YP_RLE_SRC_FLOATS 10240   // staged source sub-block (40 KiB at most)
@@ -44,7 +41,7 @@ struct RleArgs {
   uint32_t* counts;         // [B,max_dets,cap]
   int32_t* rle_len;         // [B,max_dets]
   int max_dets, ph, pw, out_h, out_w, cap, order;
-  int ncols;                // columns per batch: multiple of 16, <= 64, ncols * ceil(out_h/64) <= YP_RLE_CELLS
+  int ncols;                // columns per batch: multiple of the waves per workgroup, <= 64, ncols * ceil(out_h/64) <= threads
   int ws;                   // staged source columns per batch (0: not staged, phase A reads global memory)
   float threshold;
   double scale_x, scale_y;  // 1. / ((double)dst / src), as cv::resize computes them
@@ -75,10 +72,12 @@ __device__ __forceinline__ int wave_incl_max(int v, int lane) {
 // Dynamic LDS, carved by the kernel (sizes from the launch arguments):
 //   src   [ph][ws] float            staged source sub-block
 //   hcol  [16][ph] float|int        OpenCV's row buffer, one per wave
-//   bits  [YP_RLE_CELLS] u64        the batch's bitmap, [column][chunk]
+//   bits  [THREADS] u64             the batch's bitmap, [column][chunk]
 //   wsum, wmax [16] int             the scan's per-wave totals
 //   fy/sy [out_h]                   vertical coefficients
-__global__ __launch_bounds__(YP_RLE_THREADS) void mask_rle_kernel(const RleArgs p) {
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void mask_rle_kernel(const RleArgs p) {
+  constexpr int NWAVES = THREADS / YP_WAVE;   // (the cells of a batch - columns x 64-row chunks - number at most THREADS)
   extern __shared__ __align__(16) char rle_lds[];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int n = blockIdx.x, b = blockIdx.y;
@@ -90,15 +89,16 @@ __global__ __launch_bounds__(YP_RLE_THREADS) void mask_rle_kernel(const RleArgs 
   const int HB = (p.out_h + 63) >> 6;
   char* lp_ = rle_lds;
   float* const s_src = reinterpret_cast<float*>(lp_);                 lp_ += (size_t)((p.ph * p.ws * 4 + 15) & ~15);
-  float* const s_hcol = reinterpret_cast<float*>(lp_) + wave * p.ph;  lp_ += (size_t)((YP_RLE_WAVES * p.ph * 4 + 15) & ~15);
-  u64* const s_bits = reinterpret_cast<u64*>(lp_);                    lp_ += YP_RLE_CELLS * 8;
-  int* const s_wsum = reinterpret_cast<int*>(lp_);                    lp_ += YP_RLE_WAVES * 4;
-  int* const s_wmax = reinterpret_cast<int*>(lp_);                    lp_ += YP_RLE_WAVES * 4;
+  float* const s_hcol = reinterpret_cast<float*>(lp_) + wave * p.ph;  lp_ += (size_t)((NWAVES * p.ph * 4 + 15) & ~15);
+  u64* const s_bits = reinterpret_cast<u64*>(lp_);                    lp_ += THREADS * 8;
+  int* const s_wsum = reinterpret_cast<int*>(lp_);                    lp_ += NWAVES * 4;
+  int* const s_wmax = reinterpret_cast<int*>(lp_);                    lp_ += NWAVES * 4;
   float* const s_fy = reinterpret_cast<float*>(lp_);                  lp_ += (size_t)p.out_h * 4;
   short* const s_sy = reinterpret_cast<short*>(lp_);                  lp_ += (size_t)((p.out_h * 2 + 15) & ~15);
   int* const s_clo = reinterpret_cast<int*>(lp_);                     lp_ += 64 * 4;   // first / last source row a 64-row chunk reads
   int* const s_chi = reinterpret_cast<int*>(lp_);                     lp_ += 64 * 4;
-  int* const s_colnz = reinterpret_cast<int*>(lp_);                   // [ws] 1 = the staged source column holds a non-zero value
+  int* const s_colnz = reinterpret_cast<int*>(lp_);                   lp_ += (size_t)(p.pw + 4) * 4;   // [pw] 1 = the source column holds a non-zero value
+  int* const s_colpre = reinterpret_cast<int*>(lp_);                  // [pw+1] exclusive prefix sums of s_colnz
   int* const s_hcol_i = reinterpret_cast<int*>(s_hcol);
 
   const float* __restrict__ S = p.masks + slot * (size_t)p.ph * p.pw;
@@ -112,7 +112,7 @@ __global__ __launch_bounds__(YP_RLE_THREADS) void mask_rle_kernel(const RleArgs 
   // vertical coefficients of every output row (weights kept, row indices clipped at use).  (Keeping them
   // in registers per lane instead was slower: 16 unrolled chunks spilled at the 128 VGPRs a 1024-thread
   // workgroup is allowed - 2.6 ms against 1.7 at config 2.)
-  for (int y = t; y < p.out_h; y += YP_RLE_THREADS) {
+  for (int y = t; y < p.out_h; y += THREADS) {
     float f = (float)(((double)y + 0.5) * p.scale_y - 0.5);
     const int s = (int)floorf(f);
     s_fy[y] = f - (float)s;
@@ -130,9 +130,34 @@ __global__ __launch_bounds__(YP_RLE_THREADS) void mask_rle_kernel(const RleArgs 
     s_chi[t] = min(max((int)s_sy[min(t * 64 + 63, p.out_h - 1)] + 1, 0), phm1);
   }
   const u64 all_chunks = HB >= 64 ? ~0ull : ((1ull << HB) - 1ull);
+  for (int c = t; c < p.pw; c += THREADS) s_colnz[c] = 0;
   __syncthreads();
+  if (skip_ok) {
+    // one pass over the whole mask, all loads in flight at once: which source columns hold anything.  The
+    // batches of output columns that read only empty ones are then passed over without touching memory.
+    const int np = p.ph * p.pw;
+    int c = t % p.pw;
+    const int cstep = THREADS % p.pw;
+    for (int idx = t; idx < np; idx += THREADS) {
+      if (S[idx] != 0.0f) s_colnz[c] = 1;          // (every writer stores the same value)
+      c += cstep;
+      c = c >= p.pw ? c - p.pw : c;
+    }
+    __syncthreads();
+    if (wave == 0) {                               // exclusive prefix sums, 64 columns per step
+      int run = 0;
+      for (int c0 = 0; c0 < p.pw; c0 += 64) {
+        const int v = c0 + lane < p.pw ? s_colnz[c0 + lane] : 0;
+        const int incl = wave_incl_add(v, lane);
+        if (c0 + lane < p.pw) s_colpre[c0 + lane] = run + incl - v;
+        run += __shfl(incl, 63);
+      }
+      if (lane == 0) s_colpre[p.pw] = run;
+    }
+    __syncthreads();
+  }
 
-  const int cpw = p.ncols / YP_RLE_WAVES;        // columns per wave and batch
+  const int cpw = p.ncols / NWAVES;        // columns per wave and batch
   int total = 0;              // boundaries before the current batch (identical in every thread)
   int last_pos = 0;           // position of the last boundary so far (0: none yet)
   int prev_lastbit = 0;       // bit of the last pixel of the previous column
@@ -140,19 +165,30 @@ __global__ __launch_bounds__(YP_RLE_THREADS) void mask_rle_kernel(const RleArgs 
     const int nc = min(p.ncols, p.out_w - x0);   // columns in this batch
     // ---- S: stage the source columns this batch reads ----------------------------------------------
     int sx_lo = 0;
-    if (p.ws > 0 && !identity) {
+    if (!identity) {
       float f_; bool r_;
       linear_coeff_x(x0, p.scale_x, p.pw, sx_lo, f_, r_);
-      const int wcols = min(p.ws, p.pw - sx_lo);
-      if (skip_ok) {
-        if (t < p.ws) s_colnz[t] = 0;
-        __syncthreads();
+      if (skip_ok && prev_lastbit == 0) {
+        int sx_hi;
+        linear_coeff_x(x0 + nc - 1, p.scale_x, p.pw, sx_hi, f_, r_);
+        sx_hi = min(sx_hi + 1, p.pw - 1);
+        if (s_colpre[sx_hi + 1] - s_colpre[sx_lo] == 0) {
+          // the whole batch is zero and so was the pixel before it: no bit, no boundary, nothing to count
+          if (bitmap) {
+            for (int idx = t; idx < p.out_h * YP_RLE_MAX_COLS; idx += THREADS) {
+              const int y = idx >> 6, xc = idx & 63;
+              if (xc < nc) bitmap[(size_t)y * p.out_w + x0 + xc] = 0;
+            }
+          }
+          continue;                               // (workgroup-uniform, and no barrier is passed over)
+        }
       }
-      for (int idx = t; idx < p.ph * wcols; idx += YP_RLE_THREADS) {
+    }
+    if (p.ws > 0 && !identity) {
+      const int wcols = min(p.ws, p.pw - sx_lo);
+      for (int idx = t; idx < p.ph * wcols; idx += THREADS) {
         const int r = idx / wcols, c = idx - r * wcols;
-        const float v = S[(size_t)r * p.pw + sx_lo + c];
-        s_src[r * p.ws + c] = v;
-        if (skip_ok && v != 0.0f) s_colnz[c] = 1;     // (every writer stores the same value)
+        s_src[r * p.ws + c] = S[(size_t)r * p.pw + sx_lo + c];
       }
       __syncthreads();
     }
@@ -168,7 +204,7 @@ __global__ __launch_bounds__(YP_RLE_THREADS) void mask_rle_kernel(const RleArgs 
         const float a0 = one - fx, a1 = fx;
         const int ia0 = (int)rintf(a0 * cscale), ia1 = (int)rintf(a1 * cscale);   // saturate_cast<short>: cvRound
         const int sx1 = min(sx + 1, p.pw - 1);
-        if (skip_ok && p.ws > 0 && s_colnz[sx - sx_lo] == 0 && s_colnz[sx1 - sx_lo] == 0) {   // wave-uniform
+        if (skip_ok && s_colnz[sx] == 0 && s_colnz[sx1] == 0) {   // wave-uniform
           if (lane < HB) s_bits[col * HB + lane] = 0ull;
           continue;
         }
@@ -263,7 +299,7 @@ __global__ __launch_bounds__(YP_RLE_THREADS) void mask_rle_kernel(const RleArgs 
       __syncthreads();
       int base = 0, basemax = -1, btot = 0, bmax = -1;
 #pragma unroll
-      for (int w = 0; w < YP_RLE_WAVES; ++w) {
+      for (int w = 0; w < NWAVES; ++w) {
         const int ws_ = s_wsum[w], wm_ = s_wmax[w];
         if (w < wave) { base += ws_; basemax = max(basemax, wm_); }
         btot += ws_; bmax = max(bmax, wm_);
@@ -285,7 +321,7 @@ __global__ __launch_bounds__(YP_RLE_THREADS) void mask_rle_kernel(const RleArgs 
     }
     // ---- the row-major bitmap: nc bytes of every row per batch (train.py:502-506's detection_masks) ----
     if (bitmap) {
-      for (int idx = t; idx < p.out_h * YP_RLE_MAX_COLS; idx += YP_RLE_THREADS) {
+      for (int idx = t; idx < p.out_h * YP_RLE_MAX_COLS; idx += THREADS) {
         const int y = idx >> 6, xc = idx & 63;
         if (xc < nc) bitmap[(size_t)y * p.out_w + x0 + xc] = (uint8_t)((s_bits[xc * HB + (y >> 6)] >> (y & 63)) & 1ull);
       }
@@ -309,22 +345,27 @@ hipError_t yp_launch_mask_rle(int batch, int max_dets, int ph, int pw, const flo
   a.scale_x = 1.0 / ((double)out_w / (double)pw);
   a.scale_y = 1.0 / ((double)out_h / (double)ph);
   const int HB = (out_h + 63) / 64;
+  // 512 threads (two or more workgroups per CU overlap each other's barriers and round trips: at 138x138 ->
+  // 550x550 an all-zero mask costs 0.24 ms per 3200 detections with one 1024-thread workgroup per CU) while a
+  // batch of >= 32 columns fits its one-thread-per-cell phase; else 1024
+  const int threads = 32 * HB <= 512 ? 512 : 1024;
+  const int nwaves = threads / YP_WAVE;
   int nc = YP_RLE_MAX_COLS;
-  while (nc > 16 && nc * HB > YP_RLE_CELLS) nc -= 16;
+  while (nc > nwaves && nc * HB > threads) nc -= nwaves;
   // staged source sub-block: columns sx(x0) .. sx(x0+nc-1)+1, at most floor(nc*scale)+3 of them
   auto width = [&](int ncols) { return (int)((double)ncols * a.scale_x) + 3; };
-  while (nc > 16 && (long long)ph * width(nc) > YP_RLE_SRC_FLOATS) nc -= 16;
+  while (nc > nwaves && (long long)ph * width(nc) > YP_RLE_SRC_FLOATS) nc -= nwaves;
   a.ncols = nc;
   a.ws = (long long)ph * width(nc) <= YP_RLE_SRC_FLOATS ? (width(nc) < pw ? width(nc) : pw) : 0;
-  static bool attr_set = false;
-  if (!attr_set) {   // up to ~113 KiB of dynamic LDS at the largest supported sizes
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mask_rle_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
+  const size_t lds = (size_t)((ph * a.ws * 4 + 15) & ~15) + (size_t)((nwaves * ph * 4 + 15) & ~15) + (size_t)threads * 8 +
+                     2 * (size_t)nwaves * 4 + (size_t)out_h * 4 + (size_t)((out_h * 2 + 15) & ~15) + 2 * 64 * 4 + (size_t)(2 * pw + 8) * 4 + 16;
+  const void* kern = threads == 512 ? reinterpret_cast<const void*>(&mask_rle_kernel<512>) : reinterpret_cast<const void*>(&mask_rle_kernel<1024>);
+  if (lds > 48 * 1024) {   // (up to ~113 KiB at the largest supported sizes; per call: the attribute belongs to the current device)
+    const hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
   }
-  const size_t lds = (size_t)((ph * a.ws * 4 + 15) & ~15) + (size_t)((YP_RLE_WAVES * ph * 4 + 15) & ~15) + YP_RLE_CELLS * 8 +
-                     2 * YP_RLE_WAVES * 4 + (size_t)out_h * 4 + (size_t)((out_h * 2 + 15) & ~15) + 2 * 64 * 4 + (size_t)(a.ws + 4) * 4 + 16;
-  hipLaunchKernelGGL(mask_rle_kernel, dim3(max_dets, batch), dim3(YP_RLE_THREADS), lds, st, a);
-  return hipGetLastError();
+  void* args[] = {&a};
+  return hipLaunchKernel(kern, dim3(max_dets, batch), dim3(threads), args, lds, st);
 }
 
 int yp_rle_limits(int* max_src_h, int* max_out_h) {
