@@ -267,6 +267,33 @@ def test_per_class_group_pool_cut_to_max_dets(torch_cuda, max_dets):
     assert (ref["num_detections"] == max_dets).all()
 
 
+@pytest.mark.parametrize("num_classes,conf", [(81, 0.05), (81, 0.3), (7, 0.05), (200, 0.01), (3, 0.5)])
+def test_early_rejects_never_drop_an_anchor_at_the_threshold(torch_cuda, num_classes, conf):
+    """score_filter's two exact-safe rejects (1/(1+exp(x_bg-xf)) and the Jensen bound on the other classes)
+    against rows built to sit AT the confidence threshold: the background logit is solved so that the best
+    foreground probability is conf * (1 +- 1e-6 ... 1e-2), with the other logits tightly bunched (where the
+    Jensen bound is sharpest), widely spread, and shifted by large offsets (|x| up to ~120, beyond which the
+    second reject switches itself off).  The survivor count and every output must equal the C oracle's."""
+    from yolact_amd import synth
+    rng = np.random.default_rng(40 + num_classes)
+    net, shp = synth.make_toy(26, batch=2, fmaps=((16, 16), (4, 4)), num_classes=num_classes)     # A = 816
+    cls = net["pred_cls"].astype(np.float64)
+    B, A, C = cls.shape
+    spread = rng.choice([1e-3, 0.05, 1.0, 4.0], (B, A, 1))
+    x = rng.normal(0.0, 1.0, (B, A, C)) * spread
+    x[..., 1] += rng.uniform(0.0, 6.0, (B, A))                                      # class 1 is the best foreground class
+    f = x[..., 1:].max(-1)
+    others = np.exp(x[..., 1:] - f[..., None]).sum(-1)                              # sum over fg of exp(x - f), >= 1
+    rel = rng.choice([-1e-2, -1e-4, -1e-6, 1e-6, 1e-4, 1e-2], (B, A))
+    target = np.minimum(conf * (1.0 + rel), 0.999 / others)                         # p_fgmax = 1 / (others + exp(x0 - f))
+    x[..., 0] = f + np.log(np.maximum(1.0 / target - others, 1e-30))
+    x += rng.choice([0.0, 0.0, 30.0, -60.0, 110.0, -125.0, 300.0], (B, A, 1))        # softmax is shift-invariant; the kernel's sums are not
+    net["pred_cls"] = x.astype(np.float32)
+    for mode, top_k, md in (("per_class", 100, 50), ("cc", 200, 100)):
+        got, ref = check_vs_c_oracle(torch_cuda, net, shp, mode=mode, top_k=top_k, max_dets=md, conf=conf, label=f"edge-C{num_classes}")
+    assert 0.2 * A < ref["num_survivors"].min() and ref["num_survivors"].max() < 0.8 * A      # both sides of the threshold are populated
+
+
 def test_more_work_items_than_resident_waves(torch_cuda):
     """4000 small images: score_filter has more work items than resident waves and walks them
     grid-stride; every NMS workgroup finds one list per image."""
