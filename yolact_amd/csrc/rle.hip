@@ -43,6 +43,7 @@ struct RleArgs {
   int max_dets, ph, pw, out_h, out_w, cap, order;
   int ncols;                // columns per batch: multiple of the waves per workgroup, <= 64, ncols * ceil(out_h/64) <= threads
   int ws;                   // staged source columns per batch (0: not staged, phase A reads global memory)
+  int all_bits;             // 1: the whole image's bitmap bits are kept in LDS and the row-major bitmap is written at the end
   float threshold;
   double scale_x, scale_y;  // 1. / ((double)dst / src), as cv::resize computes them
 };
@@ -98,7 +99,9 @@ __global__ __launch_bounds__(THREADS) void mask_rle_kernel(const RleArgs p) {
   int* const s_clo = reinterpret_cast<int*>(lp_);                     lp_ += 64 * 4;   // first / last source row a 64-row chunk reads
   int* const s_chi = reinterpret_cast<int*>(lp_);                     lp_ += 64 * 4;
   int* const s_colnz = reinterpret_cast<int*>(lp_);                   lp_ += (size_t)(p.pw + 4) * 4;   // [pw] 1 = the source column holds a non-zero value
-  int* const s_colpre = reinterpret_cast<int*>(lp_);                  // [pw+1] exclusive prefix sums of s_colnz
+  int* const s_colpre = reinterpret_cast<int*>(lp_);                  lp_ += (size_t)(((p.pw + 2) * 4 + 15) & ~15);   // [pw+1] exclusive prefix sums of s_colnz
+  lp_ = rle_lds + (((size_t)(lp_ - rle_lds) + 15) & ~(size_t)15);
+  u64* const s_all = reinterpret_cast<u64*>(lp_);                     // [HB][apitch] all bitmap bits (all_bits only)
   int* const s_hcol_i = reinterpret_cast<int*>(s_hcol);
 
   const float* __restrict__ S = p.masks + slot * (size_t)p.ph * p.pw;
@@ -130,7 +133,10 @@ __global__ __launch_bounds__(THREADS) void mask_rle_kernel(const RleArgs p) {
     s_chi[t] = min(max((int)s_sy[min(t * 64 + 63, p.out_h - 1)] + 1, 0), phm1);
   }
   const u64 all_chunks = HB >= 64 ? ~0ull : ((1ull << HB) - 1ull);
+  const int apitch = (p.out_w + 3) & ~3;         // cells per chunk row of s_all: four cells = 32 bytes, read as two 16-byte loads
   for (int c = t; c < p.pw; c += THREADS) s_colnz[c] = 0;
+  if (bitmap && p.all_bits)
+    for (int i = t; i < HB * apitch; i += THREADS) s_all[i] = 0ull;
   __syncthreads();
   if (skip_ok) {
     // one pass over the whole mask, all loads in flight at once: which source columns hold anything.  The
@@ -174,7 +180,7 @@ __global__ __launch_bounds__(THREADS) void mask_rle_kernel(const RleArgs p) {
         sx_hi = min(sx_hi + 1, p.pw - 1);
         if (s_colpre[sx_hi + 1] - s_colpre[sx_lo] == 0) {
           // the whole batch is zero and so was the pixel before it: no bit, no boundary, nothing to count
-          if (bitmap) {
+          if (bitmap && !p.all_bits) {
             for (int idx = t; idx < p.out_h * YP_RLE_MAX_COLS; idx += THREADS) {
               const int y = idx >> 6, xc = idx & 63;
               if (xc < nc) bitmap[(size_t)y * p.out_w + x0 + xc] = 0;
@@ -279,6 +285,7 @@ __global__ __launch_bounds__(THREADS) void mask_rle_kernel(const RleArgs p) {
       const int ccol = have ? t / HB : 0, cc = have ? t - ccol * HB : 0;
       const int cell_start = (x0 + ccol) * p.out_h + cc * 64;
       const u64 m = have ? s_bits[t] : 0ull;
+      if (have && bitmap && p.all_bits) s_all[cc * apitch + x0 + ccol] = m;
       const u64 pm = s_bits[max(min(t, ncell) - 1, 0)];            // the cell before this one in column-major order
       const int nvalid = min(64, p.out_h - cc * 64);
       const u64 vmask = nvalid == 64 ? ~0ull : ((1ull << nvalid) - 1ull);
@@ -320,13 +327,42 @@ __global__ __launch_bounds__(THREADS) void mask_rle_kernel(const RleArgs p) {
       prev_lastbit = (int)((s_bits[ncell - 1] >> (nv_last - 1)) & 1ull);
     }
     // ---- the row-major bitmap: nc bytes of every row per batch (train.py:502-506's detection_masks) ----
-    if (bitmap) {
+    if (bitmap && !p.all_bits) {
       for (int idx = t; idx < p.out_h * YP_RLE_MAX_COLS; idx += THREADS) {
         const int y = idx >> 6, xc = idx & 63;
         if (xc < nc) bitmap[(size_t)y * p.out_w + x0 + xc] = (uint8_t)((s_bits[xc * HB + (y >> 6)] >> (y & 63)) & 1ull);
       }
     }
     __syncthreads();                             // LDS is rewritten by the next batch
+  }
+  if (bitmap && p.all_bits) {
+    // The row-major bitmap (train.py:502-506's detection_masks), from the bits of the whole image in LDS.  A
+    // thread takes the cells of four adjacent columns of one 64-row chunk (two 16-byte LDS loads) and walks
+    // down their rows: one bit-field extract per pixel, one 4-byte store per row; consecutive lanes hold
+    // consecutive column groups, so a wave writes 256 contiguous bytes of a row at a time.  (Written per batch,
+    // 56 bytes of every row at a time, and then with the row and column recomputed for every four pixels, this
+    // variant spent 0.5 ms per 3200 detections in its ~11 instructions per pixel.)
+    typedef uint32_t __attribute__((aligned(1))) u32_any;   // rows start at any byte; gfx950 stores unaligned dwords
+    __syncthreads();
+    const int g4 = (p.out_w + 3) >> 2;
+    for (int item = t; item < HB * g4; item += THREADS) {
+      const int c = item / g4, x = (item - c * g4) << 2;
+      const ulonglong2* cell = reinterpret_cast<const ulonglong2*>(s_all + c * apitch + x);
+      const ulonglong2 c01 = cell[0], c23 = cell[1];
+      const int nrow = min(64, p.out_h - c * 64);
+      uint8_t* dst = bitmap + (size_t)(c * 64) * p.out_w + x;
+      const int nb = min(4, p.out_w - x);                    // valid columns of the group (4 except at the right edge)
+      auto rows = [&](uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, int n) {
+        for (int r = 0; r < n; ++r) {
+          const uint32_t v = ((w0 >> r) & 1u) | (((w1 >> r) & 1u) << 8) | (((w2 >> r) & 1u) << 16) | (((w3 >> r) & 1u) << 24);
+          if (nb == 4) *reinterpret_cast<u32_any*>(dst) = v;
+          else for (int i = 0; i < nb; ++i) dst[i] = (uint8_t)((v >> (8 * i)) & 0xffu);
+          dst += p.out_w;
+        }
+      };
+      rows((uint32_t)c01.x, (uint32_t)c01.y, (uint32_t)c23.x, (uint32_t)c23.y, min(nrow, 32));
+      rows((uint32_t)(c01.x >> 32), (uint32_t)(c01.y >> 32), (uint32_t)(c23.x >> 32), (uint32_t)(c23.y >> 32), nrow - 32);
+    }
   }
   if (t == 0) {
     const int N = p.out_h * p.out_w;
@@ -357,8 +393,11 @@ hipError_t yp_launch_mask_rle(int batch, int max_dets, int ph, int pw, const flo
   while (nc > nwaves && (long long)ph * width(nc) > YP_RLE_SRC_FLOATS) nc -= nwaves;
   a.ncols = nc;
   a.ws = (long long)ph * width(nc) <= YP_RLE_SRC_FLOATS ? (width(nc) < pw ? width(nc) : pw) : 0;
-  const size_t lds = (size_t)((ph * a.ws * 4 + 15) & ~15) + (size_t)((nwaves * ph * 4 + 15) & ~15) + (size_t)threads * 8 +
-                     2 * (size_t)nwaves * 4 + (size_t)out_h * 4 + (size_t)((out_h * 2 + 15) & ~15) + 2 * 64 * 4 + (size_t)(2 * pw + 8) * 4 + 16;
+  // the whole image's bits in LDS when a bitmap is wanted and they take at most 64 KiB (two workgroups per CU)
+  const size_t all_bytes = (size_t)HB * ((out_w + 3) & ~3) * 8;
+  a.all_bits = (bitmaps != nullptr && all_bytes <= 64 * 1024) ? 1 : 0;
+  const size_t lds = (a.all_bits ? all_bytes : 0) + (size_t)((ph * a.ws * 4 + 15) & ~15) + (size_t)((nwaves * ph * 4 + 15) & ~15) + (size_t)threads * 8 +
+                     2 * (size_t)nwaves * 4 + (size_t)out_h * 4 + (size_t)((out_h * 2 + 15) & ~15) + 2 * 64 * 4 + (size_t)(pw + 4) * 4 + (size_t)(((pw + 2) * 4 + 15) & ~15) + 32;
   const void* kern = threads == 512 ? reinterpret_cast<const void*>(&mask_rle_kernel<512>) : reinterpret_cast<const void*>(&mask_rle_kernel<1024>);
   if (lds > 48 * 1024) {   // (up to ~113 KiB at the largest supported sizes; per call: the attribute belongs to the current device)
     const hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
