@@ -142,12 +142,30 @@ __global__ __launch_bounds__(THREADS) void mask_rle_kernel(const RleArgs p) {
     // one pass over the whole mask, all loads in flight at once: which source columns hold anything.  The
     // batches of output columns that read only empty ones are then passed over without touching memory.
     const int np = p.ph * p.pw;
-    int c = t % p.pw;
-    const int cstep = THREADS % p.pw;
-    for (int idx = t; idx < np; idx += THREADS) {
-      if (S[idx] != 0.0f) s_colnz[c] = 1;          // (every writer stores the same value)
-      c += cstep;
-      c = c >= p.pw ? c - p.pw : c;
+    if ((np & 3) == 0 && (reinterpret_cast<uintptr_t>(S) & 15u) == 0) {   // 16 bytes per load
+      const float4* S4 = reinterpret_cast<const float4*>(S);
+      int c = (4 * t) % p.pw;
+      const int cstep = (4 * THREADS) % p.pw;
+      for (int i = t; i < (np >> 2); i += THREADS) {
+        const float4 v = S4[i];
+        int c1 = c + 1; c1 = c1 >= p.pw ? c1 - p.pw : c1;
+        int c2 = c1 + 1; c2 = c2 >= p.pw ? c2 - p.pw : c2;
+        int c3 = c2 + 1; c3 = c3 >= p.pw ? c3 - p.pw : c3;
+        if (v.x != 0.0f) s_colnz[c] = 1;           // (every writer stores the same value)
+        if (v.y != 0.0f) s_colnz[c1] = 1;
+        if (v.z != 0.0f) s_colnz[c2] = 1;
+        if (v.w != 0.0f) s_colnz[c3] = 1;
+        c += cstep;
+        c = c >= p.pw ? c - p.pw : c;
+      }
+    } else {
+      int c = t % p.pw;
+      const int cstep = THREADS % p.pw;
+      for (int idx = t; idx < np; idx += THREADS) {
+        if (S[idx] != 0.0f) s_colnz[c] = 1;
+        c += cstep;
+        c = c >= p.pw ? c - p.pw : c;
+      }
     }
     __syncthreads();
     if (wave == 0) {                               // exclusive prefix sums, 64 columns per step
