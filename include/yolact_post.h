@@ -220,6 +220,14 @@ int yp_assemble_masks_backward(int32_t device_id, int32_t batch, int32_t rows, i
  * negative YP_E* code.  Pure host code, no device needed. */
 int yp_rle_string(const uint32_t* counts, int32_t n, char* out, int32_t cap);
 
+/* The same for n_lists lists at once: list i is the lens[i] counts from counts[starts[i]] on, in a HOST array of
+ * n_counts counts (any layout: rows of a matrix, or the lists packed back to back).  The strings are written back
+ * to back, each NUL-terminated, string i at out + offsets[i]; offsets has n_lists + 1 entries.  Returns the bytes
+ * all strings need (> out_cap: they did not fit; 7*sum(lens) + n_lists always suffices), or a negative YP_E*
+ * code.  One call per batch instead of one per detection. */
+int64_t yp_rle_strings(const uint32_t* counts, const int64_t* starts, const int32_t* lens, int32_t n_lists,
+                       int64_t n_counts, char* out, int64_t out_cap, int64_t* offsets);
+
 /* Bytes of device scratch the handle holds. */
 int64_t yp_scratch_bytes(const yp_handle* h);
 

@@ -111,3 +111,32 @@ def test_loss_mask_backward_oracle_against_finite_differences():
     cp, cc = c_oracle.loss_masks_backward(*f4)
     ap, ac = po.loss_mask_assembly_backward(*[x.astype(np.float64) for x in f4])
     assert np.abs(cp - ap).max() <= 1e-5 and np.abs(cc - ac).max() <= 1e-4
+
+
+def test_batched_rle_strings_match_the_oracle_and_the_single_call():
+    """yp_rle_strings (host code of the library, no device needed): many count lists in one call give the
+    strings of pycocotools' rleToString restatement, list by list; empty lists give empty strings; a buffer
+    that is too small is reported by the returned size."""
+    import ctypes
+    from oracle import consumer_oracle as co
+    from yolact_amd import _lib, consumer
+    rng = np.random.default_rng(9)
+    n, stride = 40, 64
+    lens = rng.integers(0, stride + 1, n).astype(np.int32); lens[3] = 0; lens[7] = stride
+    counts = rng.integers(0, 400000, (n, stride)).astype(np.uint32)
+    counts[5, :4] = [0, 1, 2**31, 5]                         # large differences, both signs
+    got = consumer.rle_strings(counts, lens)
+    for i in range(n):
+        assert got[i] == co.rle_to_string(counts[i, :lens[i]]), i
+        assert got[i] == consumer.rle_string(counts[i, :lens[i]])
+    L = _lib.load()
+    need = sum(len(x) + 1 for x in got)
+    buf = ctypes.create_string_buffer(16); offs = np.zeros(n + 1, np.int64)
+    starts = np.arange(n, dtype=np.int64) * stride
+    assert L.yp_rle_strings(counts.ctypes.data, starts.ctypes.data, lens.ctypes.data, n, counts.size, ctypes.addressof(buf), 16, offs.ctypes.data) == need
+    bad = lens.copy(); bad[n - 1] = stride + 1                 # would run past the end of the array
+    assert L.yp_rle_strings(counts.ctypes.data, starts.ctypes.data, bad.ctypes.data, n, counts.size, ctypes.addressof(buf), 16, offs.ctypes.data) < 0
+    # packed back to back
+    flat = np.concatenate([counts[i, :lens[i]] for i in range(n)])
+    pst = np.concatenate([[0], np.cumsum(lens[:-1])]).astype(np.int64)
+    assert consumer.rle_strings(flat, lens, pst) == got

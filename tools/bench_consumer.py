@@ -54,6 +54,14 @@ def main():
         co.rle_counts(co.mask_to_bitmap(m[i], cfg.img_h, cfg.img_w))
     t = time.perf_counter() - t0
     res["cpu_numpy_restatement"] = {"detections_per_s": round(16 / t, 1), "sample": "16 detections, one core"}
+    # F3: the whole export (coco_eval.py:123-155): device resize + RLE, one copy of the counts, one encoder call, dicts
+    ids = list(range(B)); hw = [(cfg.img_h, cfg.img_w)] * B
+    consumer.export_detections(out, ids, hw)
+    t0 = time.perf_counter()
+    for _ in range(3):
+        ann = consumer.export_detections(out, ids, hw)
+    t = (time.perf_counter() - t0) / 3
+    res["export_detections"] = {"ms_per_batch": round(t * 1e3, 2), "annotations": len(ann), "note": "wall clock, host included"}
     # F4: the loss's mask assembly, forward and backward, at the same shape (32 images x 100 positives, boxes
     # = the detections' boxes in pixels)
     boxes_px = (out["detection_boxes"] * torch.tensor([cfg.img_h, cfg.img_w, cfg.img_h, cfg.img_w], device="cuda", dtype=torch.float32)).contiguous()

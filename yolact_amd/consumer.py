@@ -65,14 +65,43 @@ def rle_string(counts: np.ndarray) -> str:
     return buf.value.decode("ascii")
 
 
+def rle_strings(counts: np.ndarray, lens: np.ndarray, starts: np.ndarray | None = None):
+    """The compressed ``counts`` strings of many lists at once (host; yp_rle_strings).  ``counts`` is either
+    [n, stride] (list i = the first lens[i] counts of row i) or, with ``starts``, a flat array in which list i
+    begins at starts[i].  Returns a list of n str."""
+    c = np.ascontiguousarray(counts).astype(np.uint32, copy=False)
+    ln = np.ascontiguousarray(lens, dtype=np.int32)
+    n = int(ln.shape[0])
+    if starts is None:
+        starts = np.arange(n, dtype=np.int64) * int(c.shape[1])
+    st = np.ascontiguousarray(starts, dtype=np.int64)
+    cap = 7 * int(ln.sum()) + n + 1                    # a count takes at most 7 characters
+    buf = ctypes.create_string_buffer(cap)
+    offs = np.zeros(n + 1, np.int64)
+    rc = _lib.load().yp_rle_strings(c.ctypes.data, st.ctypes.data, ln.ctypes.data, n, int(c.size), ctypes.addressof(buf), cap,
+                                    offs.ctypes.data)
+    if rc < 0:
+        _lib.check(int(rc))
+    raw = buf.raw
+    return [raw[offs[i]:offs[i + 1] - 1].decode("ascii") for i in range(n)]
+
+
 def rle_dicts(rle: dict):
     """Per image, per detection: ``{'size': [h, w], 'counts': str}`` - what ``mask.encode`` returns after
-    the ``.decode('ascii')`` of coco_eval.py:137."""
-    counts = rle["counts"].cpu().numpy().view(np.uint32)
-    lens = rle["len"].cpu().numpy()
+    the ``.decode('ascii')`` of coco_eval.py:137.  The counts in use are packed on the device, copied to the host
+    once, and encoded by one call for the whole batch."""
+    lens_d = rle["len"]
+    B, md = lens_d.shape
+    lens = lens_d.cpu().numpy()
+    width = max(int(lens.max()) if lens.size else 0, 1)
+    c2 = rle["counts"][:, :, :width].reshape(B * md, width)
+    used = torch.arange(width, device=c2.device)[None, :] < lens_d.reshape(-1, 1)
+    flat = c2[used].cpu().numpy().view(np.uint32)                       # the lists back to back, in (b, n) order
+    ln = lens.reshape(-1)
+    starts = np.concatenate([[0], np.cumsum(ln[:-1], dtype=np.int64)]) if ln.size else np.zeros(0, np.int64)
     h, w = rle["size"]
-    return [[{"size": [h, w], "counts": rle_string(counts[b, n, :lens[b, n]])} for n in range(lens.shape[1]) if lens[b, n] > 0]
-            for b in range(lens.shape[0])]
+    strs = rle_strings(flat, ln, starts)
+    return [[{"size": [h, w], "counts": strs[b * md + n]} for n in range(md) if lens[b, n] > 0] for b in range(B)]
 
 
 def export_detections(result: dict, image_ids, orig_hw, score_thresh: float = 0.05, threshold: float = 0.5):

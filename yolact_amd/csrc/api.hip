@@ -487,9 +487,9 @@ extern "C" int yp_assemble_masks_backward(int32_t device_id, int32_t batch, int3
 
 // pycocotools maskApi.c rleToString: every count (from the fourth on: its difference to the count two
 // places before) as little-endian groups of 5 bits, bit 5 = "more groups follow", offset by '0'.
-extern "C" int yp_rle_string(const uint32_t* counts, int32_t n, char* out, int32_t cap) {
-  if (!counts || !out || n < 0 || cap < 1) return fail(YP_EINVAL, "yp_rle_string: bad argument");
-  int len = 0;
+// Writes at most cap-1 characters (no terminator) and returns the full length.
+static long long rle_encode(const uint32_t* counts, int n, char* out, long long cap) {
+  long long len = 0;
   for (int i = 0; i < n; ++i) {
     long long x = (long long)counts[i];
     if (i > 2) x -= (long long)counts[i - 2];
@@ -504,8 +504,33 @@ extern "C" int yp_rle_string(const uint32_t* counts, int32_t n, char* out, int32
       ++len;
     }
   }
-  out[len < cap - 1 ? len : cap - 1] = 0;
   return len;
+}
+
+extern "C" int yp_rle_string(const uint32_t* counts, int32_t n, char* out, int32_t cap) {
+  if (!counts || !out || n < 0 || cap < 1) return fail(YP_EINVAL, "yp_rle_string: bad argument");
+  const long long len = rle_encode(counts, n, out, cap);
+  out[len < cap - 1 ? len : cap - 1] = 0;
+  return (int)len;
+}
+
+extern "C" int64_t yp_rle_strings(const uint32_t* counts, const int64_t* starts, const int32_t* lens, int32_t n_lists,
+                                  int64_t n_counts, char* out, int64_t out_cap, int64_t* offsets) {
+  if (!counts || !starts || !lens || !out || !offsets || n_lists < 0 || n_counts < 0 || out_cap < 1)
+    return fail(YP_EINVAL, "yp_rle_strings: bad argument");
+  int64_t pos = 0;
+  for (int i = 0; i < n_lists; ++i) {
+    if (lens[i] < 0 || starts[i] < 0 || starts[i] + lens[i] > n_counts)
+      return fail(YP_EINVAL, "yp_rle_strings: list %d (start %lld, %d counts) leaves the array of %lld counts", i, (long long)starts[i], lens[i],
+                  (long long)n_counts);
+    offsets[i] = pos;
+    const int64_t room = out_cap - pos;   // (<= 0 once the buffer is full: nothing more is written, the lengths still add up)
+    const long long len = rle_encode(counts + starts[i], lens[i], room > 0 ? out + pos : out, room > 0 ? room : 1);
+    if (room > 0) out[pos + (len < room - 1 ? len : room - 1)] = 0;
+    pos += len + 1;
+  }
+  offsets[n_lists] = pos;
+  return pos;
 }
 
 extern "C" int64_t yp_scratch_bytes(const yp_handle* h) { return h ? h->scratch_bytes : 0; }
