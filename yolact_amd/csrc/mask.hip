@@ -260,7 +260,7 @@ hipError_t yp_launch_mask_assemble(const yp_handle* h, int batch, const float* p
   return hipGetLastError();
 }
 
-// ---- the same kernel for the training loss (forward only) ------------------------
+// ---- the same kernel for the training loss (the gradients: loss_grad.hip) ----------
 // loss/loss_yolact.py:239-253: sigmoid(proto @ pos_coef^T) cropped by the positives' prior boxes, which
 // arrive in pixels and are normalised by the image size (L247-252) before utils.crop (L253).
 __global__ __launch_bounds__(256) void crop_edges_kernel(const float4* boxes /* [total] ymin,xmin,ymax,xmax pixels */,
