@@ -41,7 +41,13 @@ struct LossGradArgs {
 __device__ __forceinline__ float dz_of(float g, float m) { return (g * m) * (1.0f - m); }
 
 // grad_proto: a lane owns a pixel and its 32 accumulators; rows whose box misses the whole wave are skipped.
+// The image's coefficient rows and crop edges are staged in LDS by the workgroup (dynamic: rows x 36 floats)
+// and read from there as broadcasts: fetched per visited row with scalar loads, every row cost the wave a
+// dependent scalar-memory round trip before its 32 FMAs could start (67 % of the wave cycles were waits).
 __global__ __launch_bounds__(YP_LG_BLOCK) void loss_grad_proto_kernel(const LossGradArgs a, int bpi) {
+  extern __shared__ __align__(16) float lgp_lds[];
+  float4* const s_crop = reinterpret_cast<float4*>(lgp_lds);              // [rows]
+  float* const s_coef = lgp_lds + (size_t)a.rows * 4;                     // [rows][32]
   const int b = (int)blockIdx.x / bpi, blk = (int)blockIdx.x - b * bpi;
   const int p = blk * YP_LG_BLOCK + (int)threadIdx.x;
   const bool live = p < a.P;
@@ -49,8 +55,14 @@ __global__ __launch_bounds__(YP_LG_BLOCK) void loss_grad_proto_kernel(const Loss
   const int row = pc / a.pw, col = pc - row * a.pw;
   const float frow = (float)row, fcol = (float)col;
   const int N = min(a.num_rows[b], a.rows);
-  const float4* crop = a.crop + (size_t)b * a.rows;
-  const float* coef = a.coef + (size_t)b * a.rows * YP_MASK_DIM;
+  {
+    const float4* gc = a.crop + (size_t)b * a.rows;
+    const float4* gf = reinterpret_cast<const float4*>(a.coef + (size_t)b * a.rows * YP_MASK_DIM);
+    float4* sf = reinterpret_cast<float4*>(s_coef);
+    for (int i = (int)threadIdx.x; i < N; i += YP_LG_BLOCK) s_crop[i] = gc[i];
+    for (int i = (int)threadIdx.x; i < N * (YP_MASK_DIM / 4); i += YP_LG_BLOCK) sf[i] = gf[i];
+  }
+  __syncthreads();
   const float* mk = a.masks + (size_t)b * a.rows * a.P + pc;
   const float* gr = a.grad + (size_t)b * a.rows * a.P + pc;
   float acc[YP_MASK_DIM];
@@ -63,19 +75,25 @@ __global__ __launch_bounds__(YP_LG_BLOCK) void loss_grad_proto_kernel(const Loss
   const float fra = (float)ra, frb = (float)rb;
   const float fca = ra == rb ? (float)(pfirst - ra * a.pw) : 0.0f, fcb = ra == rb ? (float)(plast - rb * a.pw) : (float)(a.pw - 1);
   for (int n0 = 0; n0 < N; n0 += 64) {
-    const float4 ce = crop[min(n0 + lane, N - 1)];
+    const float4 ce = s_crop[min(n0 + lane, N - 1)];
     const bool touch = (n0 + lane < N) && (fcb >= ce.x) && (fca < ce.y) && (frb >= ce.z) && (fra < ce.w);
     unsigned long long rel = __ballot(touch);
     while (rel) {                      // wave-uniform: ascending n, as the chain's order demands
       const int n = n0 + __builtin_ctzll(rel);
       rel &= rel - 1ull;
-      const float4 cb = crop[n];
+      const float4 cb = s_crop[n];
       const bool in = live && (fcol >= cb.x) && (fcol < cb.y) && (frow >= cb.z) && (frow < cb.w);   // utils/utils.py:119-126
       float dz = 0.0f;
       if (in) dz = dz_of(gr[(size_t)n * a.P], mk[(size_t)n * a.P]);
-      const float* cf = coef + (size_t)n * YP_MASK_DIM;   // wave-uniform address
+      const float4* cf = reinterpret_cast<const float4*>(s_coef + (size_t)n * YP_MASK_DIM);   // one address for the wave: broadcasts
 #pragma unroll
-      for (int k = 0; k < YP_MASK_DIM; ++k) acc[k] = __builtin_fmaf(dz, cf[k], acc[k]);
+      for (int k = 0; k < YP_MASK_DIM; k += 4) {
+        const float4 c4 = cf[k / 4];
+        acc[k] = __builtin_fmaf(dz, c4.x, acc[k]);
+        acc[k + 1] = __builtin_fmaf(dz, c4.y, acc[k + 1]);
+        acc[k + 2] = __builtin_fmaf(dz, c4.z, acc[k + 2]);
+        acc[k + 3] = __builtin_fmaf(dz, c4.w, acc[k + 3]);
+      }
     }
   }
   if (live) {
@@ -183,7 +201,7 @@ hipError_t yp_launch_loss_grads(int batch, int rows, int ph, int pw, int img_h, 
   a.masks = masks; a.grad = grad_masks; a.gproto = grad_proto; a.gcoef = grad_coef; a.part = part;
   a.rows = rows; a.P = ph * pw; a.pw = pw; a.ph = ph;
   const int bpi = (a.P + YP_LG_BLOCK - 1) / YP_LG_BLOCK;
-  hipLaunchKernelGGL(loss_grad_proto_kernel, dim3(batch * bpi), dim3(YP_LG_BLOCK), 0, st, a, bpi);
+  hipLaunchKernelGGL(loss_grad_proto_kernel, dim3(batch * bpi), dim3(YP_LG_BLOCK), (size_t)rows * (4 + YP_MASK_DIM) * sizeof(float), st, a, bpi);
   const int pwp = (pw + 3) / 4 * 4;
   const size_t lds = ((size_t)pw * YP_MASK_DIM + (size_t)YP_GC_HALVES * pwp) * sizeof(float) + 256 * sizeof(int);
   if (lds > 48 * 1024) {   // (proto rows wider than ~350 pixels)
