@@ -223,6 +223,29 @@ def main():
     elapsed = timed(NR)              # the headline: consecutive steps write different output sets
     elapsed_same = elapsed if (args.skip_same_buffer or NR == 1) else timed(1)   # every step rewrites one set (it stays in the Infinity Cache)
 
+    # Informational: two handles on two streams taking the steps in turn (what a serving loop with two batches
+    # in flight sees: the latency-bound launches of one batch beside the bandwidth-bound ones of the other).
+    # Same steps, same rotating output sets per handle; never the headline.
+    elapsed_two = None
+    if world == 1 and not args.skip_same_buffer:
+        pp2 = PostProcessor(pc)
+        outs2 = [pp2.alloc_outputs(B) for _ in range(NR)]
+        lanes = [(pp, outs, torch.cuda.Stream(device=dev)), (pp2, outs2, torch.cuda.Stream(device=dev))]
+
+        def step2(i):
+            h, o, st = lanes[i & 1]
+            with torch.cuda.stream(st):
+                h.run(*ins, out=o[(i >> 1) % NR])
+        for i in range(2 * args.warmup):
+            step2(i)
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        for i in range(args.steps):
+            step2(i)
+        torch.cuda.synchronize(dev)
+        elapsed_two = time.perf_counter() - t1
+        del pp2, outs2, lanes
+
     # Per-kernel durations: same launches, HIP events recorded on the launch stream inside yp_run and read
     # back after every step (host-serialised, so this region is NOT the one `value` comes from).
     pp.profile(True)
@@ -256,6 +279,7 @@ def main():
         "ms_per_step": round(ms_per_step, 4),
         "value_same_buffer": round(images_per_step * args.steps / elapsed_same, 1),
         "ms_per_step_same_buffer": round(elapsed_same / args.steps * 1e3, 4),
+        "value_two_streams": round(images_per_step * args.steps / elapsed_two, 1) if elapsed_two else None,
         "config": {
             "workload": f"BASELINE config {args.config}: {cfg.img_h}x{cfg.img_w}, {A} anchors, {C} classes, "
                         f"proto {ph}x{pw}x32, {shard}, conf {cfg.conf_thresh}, top_k {top_k}, "
