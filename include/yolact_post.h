@@ -84,6 +84,17 @@ typedef struct yp_handle yp_handle;
  * YP_EINVAL, cf. the ValueError at L17-18) and allocates the device scratch. */
 int yp_create(const yp_config* cfg, yp_handle** out);
 
+/* yp_create with bounded candidate lists (no counterpart in the reference, whose tf.boolean_mask allocates
+ * per call).  yp_create sizes score_filter's key lists for the worst case - every anchor emitting
+ * min(C-1, floor(1/conf)+1) keys in per-class mode: 94 MB at 19248 anchors x 32 images of which a real
+ * batch touches under 1 MB.  Here the lists are sized for `keys_per_anchor` (>= 1) keys per anchor of a work
+ * item instead.  If a work item (a run of a few hundred consecutive anchors of one image) ever emits more, its
+ * LAST keys are dropped - the result is then that of the same image with those (anchor, class) candidates
+ * absent - and the handle's overflow flag is set.  yp_overflowed() synchronises, returns 1 if the flag was
+ * set since the last call (and clears it), 0 if not; with yp_create's worst-case lists it is always 0. */
+int yp_create_bounded(const yp_config* cfg, int32_t keys_per_anchor, yp_handle** out);
+int yp_overflowed(yp_handle* h);
+
 /* Releases the scratch.  (Python: the object going out of scope.) */
 int yp_destroy(yp_handle* h);
 

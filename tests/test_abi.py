@@ -67,6 +67,15 @@ def test_create_rejects_bad_config(kw, needle):
     assert needle in L.yp_last_error().decode()
 
 
+def test_create_bounded_rejects_a_bound_below_one():
+    import ctypes
+    from yolact_amd import _lib
+    L = _lib.load()
+    h = ctypes.c_void_p()
+    assert L.yp_create_bounded(None, 0, ctypes.byref(h)) == -1
+    assert b"keys_per_anchor" in L.yp_last_error()
+
+
 def test_create_without_gpu_fails_loudly():
     import torch
     if torch.cuda.is_available():

@@ -294,6 +294,36 @@ def test_early_rejects_never_drop_an_anchor_at_the_threshold(torch_cuda, num_cla
     assert 0.2 * A < ref["num_survivors"].min() and ref["num_survivors"].max() < 0.8 * A      # both sides of the threshold are populated
 
 
+def test_bounded_candidate_lists(torch_cuda):
+    """yp_create_bounded: lists sized for 2 keys per anchor of a work item use a fraction of the scratch and give
+    bit-identical results with no overflow on an ordinary batch; sized for 1 key per anchor on a batch in which
+    every anchor emits several keys, the overflow flag is raised (and cleared by reading it), nothing faults,
+    and the unbounded handle on the same batch does not raise it."""
+    import torch
+    from yolact_amd import PostConfig, PostProcessor, synth
+    cfg = synth.CONFIGS[2]
+    net, shp = synth.make_batch(cfg, batch=4)
+    A, C = net["pred_cls"].shape[1:]; ph, pw = net["proto_out"].shape[1:3]
+    d = {k: torch.from_numpy(v).cuda() for k, v in net.items()}
+    ins = (d["pred_offset"], d["pred_cls"], d["pred_mask_coef"], d["priors"], d["proto_out"])
+    pc = PostConfig(A, C, ph, pw, cfg.img_h, cfg.img_w, conf_thresh=cfg.conf_thresh, nms_mode="per_class", top_k=200, max_dets=100, max_batch=4)
+    full, small = PostProcessor(pc), PostProcessor(pc, keys_per_anchor=2)
+    assert small.scratch_bytes < 0.25 * full.scratch_bytes
+    a, b = full.run(*ins), small.run(*ins)
+    assert not small.overflowed() and not full.overflowed()
+    for k in a:
+        if a[k] is not None:
+            assert torch.equal(a[k], b[k]), k
+    # every anchor with five classes at p ~ 0.19: five keys per anchor
+    hot = net["pred_cls"].copy(); hot[...] = -4.0; hot[..., 1:6] = 4.0
+    ins_hot = (ins[0], torch.from_numpy(hot).cuda()) + ins[2:]
+    tiny = PostProcessor(pc, keys_per_anchor=1)
+    tiny.run(*ins_hot); full.run(*ins_hot)
+    assert tiny.overflowed() and not tiny.overflowed()
+    assert not full.overflowed()
+    assert (full.last_survivors(4) == A).all() and (tiny.last_survivors(4) == A).all()
+
+
 def test_more_work_items_than_resident_waves(torch_cuda):
     """4000 small images: score_filter has more work items than resident waves and walks them
     grid-stride; every NMS workgroup finds one list per image."""

@@ -23,7 +23,7 @@ KERNEL_NAMES = ("score_filter", "nms", "mask_assemble")
 EXPORTS = ("yp_create", "yp_destroy", "yp_run", "yp_sync", "yp_last_survivors", "yp_profile_enable",
            "yp_profile_read", "yp_scratch_bytes", "yp_last_error", "yp_version", "yp_make_priors", "yp_run_static",
            "yp_masks_to_rle", "yp_rle_string", "yp_rle_strings", "yp_assemble_masks", "yp_assemble_masks_backward",
-           "yp_assemble_masks_backward_workspace")
+           "yp_assemble_masks_backward_workspace", "yp_create_bounded", "yp_overflowed")
 
 
 class YpConfig(ctypes.Structure):
@@ -95,6 +95,10 @@ def load():
     L.yp_rle_strings.argtypes = [vp, vp, vp, ctypes.c_int32, ctypes.c_int64, vp, ctypes.c_int64, vp]
     L.yp_rle_string.restype = ctypes.c_int
     L.yp_rle_string.argtypes = [ctypes.POINTER(ctypes.c_uint32), ctypes.c_int32, ctypes.c_char_p, ctypes.c_int32]
+    L.yp_create_bounded.restype = ctypes.c_int
+    L.yp_create_bounded.argtypes = [vp, ctypes.c_int32, vp]
+    L.yp_overflowed.restype = ctypes.c_int
+    L.yp_overflowed.argtypes = [vp]
     L.yp_version.restype = ctypes.c_int
     L.yp_version.argtypes = []
     _lib = L

@@ -58,7 +58,7 @@ struct ScratchLayout {
 
 // Detect.__init__'s validation (detection.py:17-18) plus the limits of the kernels; fills the
 // host-side plan of `h` (no device memory is touched apart from attribute queries).
-static int plan_handle(const yp_config& c, yp_handle* h) {
+static int plan_handle(const yp_config& c, yp_handle* h, int kpa_bound = 0) {
   if (c.nms_thresh <= 0.0f) return fail(YP_EINVAL, "nms_threshold must be non negative.");   // detection.py:17-18
   if (c.num_anchors < 1 || c.num_anchors > (1 << 24)) return fail(YP_EINVAL, "num_anchors must be in [1, 2^24]");
   if (c.num_classes < 2 || c.num_classes > 256) return fail(YP_EINVAL, "num_classes (incl. background) must be in [2, 256]");
@@ -122,6 +122,8 @@ static int plan_handle(const yp_config& c, yp_handle* h) {
         if (lim < (double)kpa) kpa = (int)lim;
       }
     }
+    h->keys_worst = kpa;
+    if (kpa_bound > 0 && kpa_bound < kpa) kpa = kpa_bound;   // yp_create_bounded: shorter lists, overflow reported
     h->keys_per_anchor = kpa;
   }
   return YP_OK;
@@ -150,7 +152,7 @@ static ScratchLayout scratch_layout(const yp_handle* h, int max_batch) {
   L.coef = off;  off = align_up(off + B * h->sel_rows * YP_MASK_DIM * sizeof(float), 256);
   L.cnt = off;   // all counters contiguous
   L.max_items = max_items;
-  L.n_cnt = 2 * max_items + B * nseg + 2 * B;
+  L.n_cnt = 2 * max_items + B * nseg + 2 * B + 1;
   off = align_up(off + L.n_cnt * sizeof(int32_t), 256);
   L.total = off;
   return L;
@@ -167,14 +169,15 @@ static void carve_scratch(yp_handle* h, const ScratchLayout& L, void* base_ptr, 
   h->s.pool_count = h->s.seg_surv + L.max_items;
   h->s.stat_surv = h->s.pool_count + (size_t)max_batch * h->nseg;
   h->s.arrive = h->s.stat_surv + max_batch;
+  h->s.overflow = h->s.arrive + max_batch;
 }
 
-extern "C" int yp_create(const yp_config* cfg, yp_handle** out) {
+static int create_handle(const yp_config* cfg, int kpa_bound, yp_handle** out) {
   if (!cfg || !out) return fail(YP_EINVAL, "yp_create: null argument");
   *out = nullptr;
   yp_handle* h = new (std::nothrow) yp_handle();
   if (!h) return fail(YP_ENOMEM, "host allocation failed");
-  const int rc = plan_handle(*cfg, h);
+  const int rc = plan_handle(*cfg, h, kpa_bound);
   if (rc != YP_OK) { delete h; return rc; }
   DeviceGuard guard_(cfg->device_id);
   if (guard_.err != hipSuccess) { delete h; return fail(YP_EHIP, "hipSetDevice(%d) failed", cfg->device_id); }
@@ -198,6 +201,23 @@ extern "C" int yp_create(const yp_config* cfg, yp_handle** out) {
   *out = h;
   g_err[0] = 0;
   return YP_OK;
+}
+
+extern "C" int yp_create(const yp_config* cfg, yp_handle** out) { return create_handle(cfg, 0, out); }
+
+extern "C" int yp_create_bounded(const yp_config* cfg, int32_t keys_per_anchor, yp_handle** out) {
+  if (keys_per_anchor < 1) return fail(YP_EINVAL, "yp_create_bounded: keys_per_anchor must be >= 1");
+  return create_handle(cfg, keys_per_anchor, out);
+}
+
+extern "C" int yp_overflowed(yp_handle* h) {
+  if (!h) return fail(YP_EINVAL, "yp_overflowed: null handle");
+  YP_ON_DEVICE(h->cfg.device_id);
+  YP_HIP(hipStreamSynchronize(h->last_stream));
+  int32_t flag = 0;
+  YP_HIP(hipMemcpy(&flag, h->s.overflow, sizeof(flag), hipMemcpyDeviceToHost));
+  if (flag) YP_HIP(hipMemset(h->s.overflow, 0, sizeof(flag)));
+  return flag ? 1 : 0;
 }
 
 extern "C" int yp_destroy(yp_handle* h) {

@@ -135,6 +135,7 @@ struct yp_scratch {
   u64* pool;            // [max_batch][ngroups][gcap] per-class NMS survivors (per-class mode), dense per class group
   int32_t* pool_count;  // [max_batch][ngroups] (rewritten every run)
   int32_t* arrive;      // [max_batch] class groups of an image that have finished; zero between launches
+  int32_t* overflow;    // [1] set by score_filter when a work item had more keys than its list holds (yp_create_bounded)
   float4* crop;         // [max_batch][sel_rows] (x1,x2,y1,y2) crop edges in proto pixels
   float* coef;          // [max_batch][sel_rows][32] coefficients of the kept detections
 };
@@ -161,7 +162,8 @@ struct yp_handle {
   int num_cus;          // compute units of the device (256 on MI355X)
   int sf_bufb;          // score_filter: bytes of a wave's LDS tile buffer
   int sf_waves_per_cu;  // score_filter: single-wave workgroups resident per CU
-  int keys_per_anchor;  // most keys one anchor can emit: 1 (cross-class) or min(C-1, floor(1/conf)+1)
+  int keys_per_anchor;  // keys per anchor the lists are sized for: the worst case below, or yp_create_bounded's bound
+  int keys_worst;       // most keys one anchor can emit: 1 (cross-class) or min(C-1, floor(1/conf)+1)
 #ifdef YP_STAMPS
   void* dbg;            // diagnostic build only: cycle stamps
 #endif

@@ -24,6 +24,7 @@ struct ScoreFilterArgs {
   int bufb;              // bytes of the LDS tile buffer
   int fast;              // 1: stride == C and every tile starts 16-byte aligned -> wide-load path
   float conf, conf_lo;
+  int32_t* overflow;     // [1] set when an item emitted more keys than cap_item
   float pre_thresh;      // ln(1/conf - 1) + 1e-3: x_bg - x_fgmax must be below it to have p_fgmax > conf
   float jen_thr, jen_n, jen_inv_n;   // second reject: (1/conf)(1+1e-3) + 0.1 (NaN = off), C-2, 1/(C-2)
 };
@@ -362,6 +363,7 @@ __global__ __launch_bounds__(YP_WAVE, YP_SF_MIN_WAVES) void score_filter_kernel(
     if (nbuf > 0) flush();
     if (lane == 0) {
       p.seg_count[item] = nout < p.cap_item ? nout : (int)p.cap_item;
+      if (nout > p.cap_item) *p.overflow = 1;     // (bounded lists only: the item's last keys were dropped)
       p.seg_surv[item] = nsurv;
     }
     __builtin_amdgcn_s_waitcnt(0xC07F);
@@ -418,7 +420,7 @@ int yp_score_filter_waves_per_cu(const yp_handle* h) {
 hipError_t yp_launch_score_filter(const yp_handle* h, int batch, const float* pred_cls, hipStream_t st) {
   ScoreFilterArgs a;
   a.cls = pred_cls;
-  a.cand = h->s.cand; a.seg_count = h->s.seg_count; a.seg_surv = h->s.seg_surv;
+  a.cand = h->s.cand; a.seg_count = h->s.seg_count; a.seg_surv = h->s.seg_surv; a.overflow = h->s.overflow;
   a.A = h->cfg.num_anchors; a.C = h->cfg.num_classes; a.stride = h->lds_stride;
   a.conf = h->cfg.conf_thresh;
   a.conf_lo = h->cfg.conf_thresh * (1.0f - 0x1p-20f);

@@ -48,7 +48,9 @@ class PostProcessor:
     given.  One PostProcessor serves one stream at a time.
     """
 
-    def __init__(self, cfg: PostConfig):
+    def __init__(self, cfg: PostConfig, keys_per_anchor: int | None = None):
+        """``keys_per_anchor``: size the candidate lists for that many keys per anchor of a work item instead of
+        the worst case (yp_create_bounded); ``overflowed()`` then tells whether a batch lost candidates."""
         self.cfg = cfg
         self._L = _lib.load()
         c = _lib.YpConfig(
@@ -59,7 +61,10 @@ class PostProcessor:
             zero_pad_masks=int(cfg.zero_pad_masks), mask_threshold=cfg.mask_threshold,
             max_batch=cfg.max_batch, device_id=cfg.device_id)
         h = ctypes.c_void_p()
-        _lib.check(self._L.yp_create(ctypes.byref(c), ctypes.byref(h)))
+        if keys_per_anchor is None:
+            _lib.check(self._L.yp_create(ctypes.byref(c), ctypes.byref(h)))
+        else:
+            _lib.check(self._L.yp_create_bounded(ctypes.byref(c), int(keys_per_anchor), ctypes.byref(h)))
         self._h = h
         self.device = torch.device("cuda", cfg.device_id)
 
@@ -126,6 +131,13 @@ class PostProcessor:
 
     def sync(self):
         _lib.check(self._L.yp_sync(self._h))
+
+    def overflowed(self) -> bool:
+        """Synchronises; True if a candidate list overflowed since the last call (bounded lists only)."""
+        rc = int(self._L.yp_overflowed(self._h))
+        if rc < 0:
+            _lib.check(rc)
+        return rc == 1
 
     def last_survivors(self, batch: int) -> np.ndarray:
         buf = (ctypes.c_int32 * batch)()
