@@ -109,6 +109,17 @@ def test_zero_skipping_does_not_change_the_encoding(order, threshold):
     _check(masks, [8], (oh, ow), order, threshold=threshold)
 
 
+@pytest.mark.parametrize("dst", [(1100, 300), (1100, 600), (300, 1100)])
+def test_tall_and_wide_outputs_take_the_other_kernel_variants(dst):
+    """Outputs taller than 1024 rows run the 1024-thread workgroups; outputs whose bits exceed 64 KiB of LDS write
+    the bitmap batch by batch instead of once at the end.  Both threshold orders, bitmaps on."""
+    rng = np.random.default_rng(16)
+    masks = _blobs(rng, 1, 3, 20, 24)
+    masks[0, 2] = rng.random((20, 24)).astype(np.float32)           # no zero skipping to hide behind
+    for order in ("resize_then_threshold", "threshold_then_resize"):
+        _check(masks, [3], dst, order, rle_cap=dst[0] * dst[1] + 1)
+
+
 def test_counts_capacity_overflow_is_reported_and_retried():
     import torch
     from yolact_amd import _lib
