@@ -140,8 +140,9 @@ def test_pair_enumeration_used_by_the_nms_kernels():
     """csrc/nms.hip pair_sweep(): column j of the Fast NMS triangle has the j rows i < j; columns f and
     k-1-f are folded into one of k-1 rows, cut into G parts of L rows, one (folded column, part) per
     thread.  Restated here with the same integer arithmetic: every pair (i, j), i < j, exactly once, for
-    every k the kernels can meet (top_k <= 256) and both workgroup sizes."""
-    for threads in (512, 1024):
+    every k the kernels can meet (top_k <= 256), for both workgroup sizes and for the shares of a workgroup that
+    one class gets when the classes of a group are swept side by side."""
+    for threads in (7, 32, 102, 512, 1024):     # the whole workgroup, or one class's share of it
         for k in range(0, 258):
             seen = set()
             if k >= 2:

@@ -466,13 +466,15 @@ __device__ __forceinline__ bool yp_iou_gt(const float4 a, const float4 b, float 
 // the lanes of a wave share the part, so in the first column's rows they read the same box (an LDS
 // broadcast) and in the second's consecutive ones.  ~25 VALU operations per pair: the sweep is what
 // bounds a saturated image (80 classes x 200 boxes: 1.6 M pairs).
-template <int THREADS, class T>
-__device__ __forceinline__ void pair_sweep(const float4* box, T* sup, int k, float thr) {
+// (tid, nthr): the sweep is done by the nthr threads tid = 0..nthr-1 - the whole workgroup, or the share of it that
+// one class gets when the classes of a group are swept side by side.
+template <class T>
+__device__ __forceinline__ void pair_sweep(const float4* box, T* sup, int k, float thr, int tid, int nthr) {
   if (k < 2) return;
   const int nf = (k + 1) >> 1;
-  const int G = max(1, THREADS / nf);
+  const int G = max(1, nthr / nf);
   const int L = (k - 1 + G - 1) / G;
-  for (int s = threadIdx.x; s < nf * G; s += THREADS) {   // (one trip unless nf > THREADS)
+  for (int s = tid; s < nf * G; s += nthr) {   // (one trip unless nf > nthr)
     const int part = s / nf, f = s - part * nf;
     const int jb = k - 1 - f;
     const int rows = f + (jb != f ? jb : 0);               // (odd k: the middle column is folded with nothing)
@@ -552,7 +554,7 @@ __device__ __forceinline__ void finish_image(const NmsArgs& p, int b, int n, int
 template <int THREADS>
 __device__ __forceinline__ bool fast_nms_keep(const float4* sbox, int* ssup, int* s_wave_cnt, int k, float thr, int& pos, int& total) {
   const int t = threadIdx.x;
-  pair_sweep<THREADS>(sbox, ssup, k, thr);
+  pair_sweep(sbox, ssup, k, thr, t, THREADS);
   __syncthreads();
   bool keep = false;
   if (t < k) keep = ssup[t] == 0;
@@ -911,10 +913,28 @@ __device__ __forceinline__ void group_nms_body(const NmsArgs& p, int b, int g, G
   // 5. Fast NMS inside every class: a candidate survives unless a higher-ranked box of its class
   //    overlaps it by more than the threshold (detection.py:221-234; every candidate has p > conf)
   //    Class by class, the pairs (i < j) of a class dealt evenly to all threads (pair_sweep).
-  for (int c = g + 1; c <= p.nseg; c += p.ngroups) {
-    const int lo = gs.cls_off[c];
-    const int kc = min(gs.cls_cnt[c], p.top_k);
-    pair_sweep<THREADS>(gs.box + lo, gs.psup + lo, kc, p.nms_thresh);
+  //    Small classes (the usual case: a handful of candidates each) are swept side by side, every class by its
+  //    own share of the threads - one after the other the sweeps took 5.5 us of the 17 a group takes, side by side 4.4, of which ~2.7 are the
+  //    pair tests themselves (~3000 per group at config 2, ~40 VALU operations each); large ones one at a time by everybody.
+  {
+    const int ncls = (p.nseg - (g + 1)) / p.ngroups + 1;          // classes g+1, g+1+ngroups, ... <= nseg
+    int kmax = 0;
+    for (int c = g + 1; c <= p.nseg; c += p.ngroups) kmax = max(kmax, min(gs.cls_cnt[c], p.top_k));
+    const int tpc = THREADS / ncls;                               // (ncls <= 256 / ngroups... <= THREADS)
+    if (tpc >= 1 && ((kmax + 1) >> 1) <= tpc && kmax <= 64) {
+      const int ci = t / tpc, tid = t - ci * tpc;
+      if (ci < ncls) {
+        const int c = g + 1 + ci * p.ngroups;
+        const int lo = gs.cls_off[c];
+        pair_sweep(gs.box + lo, gs.psup + lo, min(gs.cls_cnt[c], p.top_k), p.nms_thresh, tid, tpc);
+      }
+    } else {
+      for (int c = g + 1; c <= p.nseg; c += p.ngroups) {
+        const int lo = gs.cls_off[c];
+        const int kc = min(gs.cls_cnt[c], p.top_k);
+        pair_sweep(gs.box + lo, gs.psup + lo, kc, p.nms_thresh, t, THREADS);
+      }
+    }
   }
   __syncthreads();
   STAMP(5);
