@@ -89,6 +89,9 @@ __device__ __forceinline__ int grp8_min(int v) {
   return v;
 }
 
+#ifndef YP_SF_AUX
+#define YP_SF_AUX 2        // cache policy of the staging loads: 2 = nt (read once, by nobody else)
+#endif
 #ifndef YP_SF_MIN_WAVES
 #define YP_SF_MIN_WAVES 1   // waves per SIMD the register allocation must allow
 #endif
@@ -152,7 +155,7 @@ __global__ __launch_bounds__(YP_WAVE, YP_SF_MIN_WAVES) void score_filter_kernel(
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(g), 0, nbytes, 0x00020000);
 #pragma unroll
     for (int u = 0; u < NLD; ++u)
-      stg[u] = __builtin_bit_cast(nat4, (raw4)__builtin_amdgcn_raw_buffer_load_b128(rsrc, lane16, u * 1024, 2 /* nt */));
+      stg[u] = __builtin_bit_cast(nat4, (raw4)__builtin_amdgcn_raw_buffer_load_b128(rsrc, lane16, u * 1024, YP_SF_AUX));
   };
 
   for (int item = blockIdx.x; item < p.nitems; item += gridDim.x) {
