@@ -27,7 +27,8 @@
  *            every multiply-add an explicit fmaf, argument clamped to [-87, 87];
  *   softmax  e_c = exp(x_c - max), S = 16 strided partial sums
  *            (s_j = e_j + e_{j+16} + ...) folded by a binary tree (8,4,2,1) -
- *            the shape of a packet reduction -, p_c = e_c / S (IEEE divide);
+ *            the shape of a packet reduction -, p_c = e_c * (1/S): ONE IEEE reciprocal
+ *            per row, then a multiply per class (Eigen's form);
  *   matmul   K-ordered fmaf chain starting from 0 (what v_mfma_f32_*_f32 and a
  *            scalar loop both compute);
  *   sigmoid  1 / (1 + exp(-x)) with the exp above and an IEEE divide;
@@ -83,8 +84,8 @@ void yo_softmax_row(const float* x, int C, float* p) {
   }
   for (int w = 8; w >= 1; w >>= 1)
     for (int j = 0; j < w; ++j) s[j] = s[j] + s[j + w];
-  float S = s[0];
-  for (int c = 0; c < C; ++c) p[c] = p[c] / S;
+  const float rS = 1.0f / s[0];                  /* exp(x - max) * reciprocal-of-sum */
+  for (int c = 0; c < C; ++c) p[c] = p[c] * rS;
 }
 
 /* utils._decode, utils/utils.py:193-213.  prior/out are [ymin,xmin,ymax,xmax]. */

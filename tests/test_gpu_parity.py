@@ -295,10 +295,12 @@ def test_early_rejects_never_drop_an_anchor_at_the_threshold(torch_cuda, num_cla
 
 
 def test_bounded_candidate_lists(torch_cuda):
-    """yp_create_bounded: lists sized for 2 keys per anchor of a work item use a fraction of the scratch and give
+    """yp_create_bounded: lists sized for 2 keys per anchor of an image use a fraction of the scratch (the
+    per-group lists are the same size in both handles; the worst-case part is the image's overflow list) and give
     bit-identical results with no overflow on an ordinary batch; sized for 1 key per anchor on a batch in which
     every anchor emits several keys, the overflow flag is raised (and cleared by reading it), nothing faults,
-    and the unbounded handle on the same batch does not raise it."""
+    and the unbounded handle on the same batch - whose class groups then take their slow path over the
+    overflow list - does not raise it."""
     import torch
     from yolact_amd import PostConfig, PostProcessor, synth
     cfg = synth.CONFIGS[2]
@@ -308,7 +310,7 @@ def test_bounded_candidate_lists(torch_cuda):
     ins = (d["pred_offset"], d["pred_cls"], d["pred_mask_coef"], d["priors"], d["proto_out"])
     pc = PostConfig(A, C, ph, pw, cfg.img_h, cfg.img_w, conf_thresh=cfg.conf_thresh, nms_mode="per_class", top_k=200, max_dets=100, max_batch=4)
     full, small = PostProcessor(pc), PostProcessor(pc, keys_per_anchor=2)
-    assert small.scratch_bytes < 0.25 * full.scratch_bytes
+    assert small.scratch_bytes < 0.4 * full.scratch_bytes
     a, b = full.run(*ins), small.run(*ins)
     assert not small.overflowed() and not full.overflowed()
     for k in a:

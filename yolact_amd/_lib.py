@@ -9,7 +9,8 @@ import ctypes
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libyolact_post.so")
+# (YOLACT_POST_LIB: experiment builds of the same sources - tools/ - under another name; never a different backend)
+LIB_PATH = os.environ.get("YOLACT_POST_LIB") or os.path.join(HERE, "libyolact_post.so")
 
 YP_NMS_CROSS_CLASS = 0
 YP_NMS_PER_CLASS = 1

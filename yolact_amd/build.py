@@ -23,17 +23,25 @@ def needs_build() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build_lib(force: bool = False, verbose: bool = False, extra_flags=()) -> str:
-    if not force and not needs_build():
+def build_lib(force: bool = False, verbose: bool = False, extra_flags=(), out: str | None = None) -> str:
+    """`out`: experiment builds (extra -D flags) under another file name, loaded with YOLACT_POST_LIB=<path>."""
+    if out is None and not force and not needs_build():
         return LIB_PATH
+    out = out or LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + FLAGS + list(extra_flags) + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB_PATH]
+    cmd = [hipcc] + FLAGS + list(extra_flags) + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", out]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
-    return LIB_PATH
+    return out
 
 
 if __name__ == "__main__":
-    build_lib(force=True, verbose=True, extra_flags=sys.argv[1:])
-    print(LIB_PATH)
+    # python -m yolact_amd.build [-o variant.so] [-DFLAG ...]
+    argv = sys.argv[1:]
+    out = None
+    if "-o" in argv:
+        i = argv.index("-o")
+        out = os.path.abspath(argv[i + 1])
+        del argv[i:i + 2]
+    print(build_lib(force=True, verbose=True, extra_flags=argv, out=out))

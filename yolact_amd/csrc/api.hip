@@ -53,7 +53,7 @@ static int env_int(const char* name, int dflt) {
 
 // Where the handle's buffers sit inside one scratch allocation of `total` bytes.
 struct ScratchLayout {
-  size_t cand, pool, crop, coef, cnt, n_cnt, max_items, total;
+  size_t lkeys, lbox, okeys, pool, pool_box, crop, sel_anchor, cnt, n_cnt, max_items, total;
 };
 
 // Detect.__init__'s validation (detection.py:17-18) plus the limits of the kernels; fills the
@@ -132,27 +132,33 @@ static int plan_handle(const yp_config& c, yp_handle* h, int kpa_bound = 0) {
 // Scratch a planned handle needs to run batches of up to `max_batch` images.
 static ScratchLayout scratch_layout(const yp_handle* h, int max_batch) {
   const bool per_class = h->cfg.nms_mode == YP_NMS_PER_CLASS;
-  const size_t B = (size_t)max_batch, nseg = (size_t)h->nseg;
-  size_t cand_keys = 0, max_items = 0;   // the largest any batch size up to max_batch needs
+  const size_t B = (size_t)max_batch;
+  size_t list_entries = 0, ovf_keys = 0, max_items = 0;   // the largest any batch size up to max_batch needs
   for (int bs = 1; bs <= max_batch; ++bs) {
-    int parts; long long cap;
-    yp_plan_items(h, bs, &parts, &cap);
+    int parts, longest;
+    long long lcap, ocap;
+    yp_plan_items(h, bs, &parts, &longest);
+    yp_plan_lists(h, bs, &lcap, &ocap);
     const size_t items = (size_t)bs * parts;
-    if (items * (size_t)cap > cand_keys) cand_keys = items * (size_t)cap;
     if (items > max_items) max_items = items;
+    if ((size_t)bs * YP_NLISTS * (size_t)lcap > list_entries) list_entries = (size_t)bs * YP_NLISTS * (size_t)lcap;
+    if ((size_t)bs * (size_t)ocap > ovf_keys) ovf_keys = (size_t)bs * (size_t)ocap;
   }
   int ngroups, gcap;
   yp_plan_groups(h, &ngroups, &gcap);
   const size_t pool_per_img = per_class ? (size_t)ngroups * gcap : 0;
   ScratchLayout L;
   size_t off = 0;
-  L.cand = off;  off = align_up(off + cand_keys * sizeof(u64), 256);
-  L.pool = off;  off = align_up(off + B * pool_per_img * sizeof(u64), 256);
-  L.crop = off;  off = align_up(off + B * h->sel_rows * sizeof(float4), 256);
-  L.coef = off;  off = align_up(off + B * h->sel_rows * YP_MASK_DIM * sizeof(float), 256);
-  L.cnt = off;   // all counters contiguous
+  L.lkeys = off;      off = align_up(off + list_entries * sizeof(u64), 256);
+  L.lbox = off;       off = align_up(off + list_entries * sizeof(float4), 256);
+  L.okeys = off;      off = align_up(off + ovf_keys * sizeof(u64), 256);
+  L.pool = off;       off = align_up(off + B * pool_per_img * sizeof(u64), 256);
+  L.pool_box = off;   off = align_up(off + B * pool_per_img * sizeof(float4), 256);
+  L.crop = off;       off = align_up(off + B * h->sel_rows * sizeof(float4), 256);
+  L.sel_anchor = off; off = align_up(off + B * h->sel_rows * sizeof(int32_t), 256);
+  L.cnt = off;   // all counters contiguous: lcount | ocount | seg_surv | pool_count | stat_surv | arrive | overflow
   L.max_items = max_items;
-  L.n_cnt = 2 * max_items + B * nseg + 2 * B + 1;
+  L.n_cnt = B * YP_NLISTS * YP_CNT_STRIDE + B * YP_CNT_STRIDE + max_items + B * YP_NLISTS + 2 * B + 1;
   off = align_up(off + L.n_cnt * sizeof(int32_t), 256);
   L.total = off;
   return L;
@@ -160,14 +166,18 @@ static ScratchLayout scratch_layout(const yp_handle* h, int max_batch) {
 
 static void carve_scratch(yp_handle* h, const ScratchLayout& L, void* base_ptr, int max_batch) {
   char* base = (char*)base_ptr;
-  h->s.cand = (u64*)(base + L.cand);
+  h->s.lkeys = (u64*)(base + L.lkeys);
+  h->s.lbox = (float4*)(base + L.lbox);
+  h->s.okeys = (u64*)(base + L.okeys);
   h->s.pool = (u64*)(base + L.pool);
+  h->s.pool_box = (float4*)(base + L.pool_box);
   h->s.crop = (float4*)(base + L.crop);
-  h->s.coef = (float*)(base + L.coef);
-  h->s.seg_count = (int32_t*)(base + L.cnt);
-  h->s.seg_surv = h->s.seg_count + L.max_items;
+  h->s.sel_anchor = (int32_t*)(base + L.sel_anchor);
+  h->s.lcount = (int32_t*)(base + L.cnt);                                   // (256-byte aligned: a line per counter)
+  h->s.ocount = h->s.lcount + (size_t)max_batch * YP_NLISTS * YP_CNT_STRIDE;
+  h->s.seg_surv = h->s.ocount + (size_t)max_batch * YP_CNT_STRIDE;
   h->s.pool_count = h->s.seg_surv + L.max_items;
-  h->s.stat_surv = h->s.pool_count + (size_t)max_batch * h->nseg;
+  h->s.stat_surv = h->s.pool_count + (size_t)max_batch * YP_NLISTS;
   h->s.arrive = h->s.stat_surv + max_batch;
   h->s.overflow = h->s.arrive + max_batch;
 }
@@ -188,7 +198,7 @@ static int create_handle(const yp_config* cfg, int kpa_bound, yp_handle** out) {
     return fail(YP_ENOMEM, "hipMalloc of %zu scratch bytes failed", L.total);
   }
   carve_scratch(h, L, h->scratch_base, cfg->max_batch);
-  if (hipMemset(h->s.seg_count, 0, L.n_cnt * sizeof(int32_t)) != hipSuccess) {   // (the arrival counters must start at zero)
+  if (hipMemset(h->s.lcount, 0, L.n_cnt * sizeof(int32_t)) != hipSuccess) {   // (the list and arrival counters must start at zero)
     (void)hipFree(h->scratch_base);
     delete h;
     return fail(YP_EHIP, "hipMemset of the counters failed");
@@ -251,12 +261,12 @@ static int run_batch(yp_handle* h, int batch, const float* pred_offset, const fl
   const bool prof = h->profile != 0;
   const bool prefill = det_masks && yp_mask_prefill(h, batch);
   if (prof) YP_HIP(hipEventRecord(h->ev[0], st));
-  YP_HIP(yp_launch_score_filter(h, batch, pred_cls, st));
+  YP_HIP(yp_launch_score_filter(h, batch, pred_cls, pred_offset, priors, st));
   if (prof) YP_HIP(hipEventRecord(h->ev[1], st));
-  YP_HIP(yp_launch_nms(h, batch, pred_offset, priors, pred_mask_coef, det_boxes, det_classes, det_scores, num_det, kept_anchor_idx,
+  YP_HIP(yp_launch_nms(h, batch, pred_offset, priors, det_boxes, det_classes, det_scores, num_det, kept_anchor_idx,
                        prefill ? det_masks : nullptr, prefill ? det_bitmaps : nullptr, yp_mask_fill_rows(h), st));
   if (prof) YP_HIP(hipEventRecord(h->ev[2], st));
-  if (det_masks) YP_HIP(yp_launch_mask_assemble(h, batch, proto, num_det, det_masks, det_bitmaps, st));
+  if (det_masks) YP_HIP(yp_launch_mask_assemble(h, batch, proto, pred_mask_coef, num_det, det_masks, det_bitmaps, st));
   if (prof) YP_HIP(hipEventRecord(h->ev[3], st));
   return YP_OK;
 }
@@ -346,7 +356,7 @@ extern "C" int yp_run_static(const yp_config* cfg, int32_t batch, const float* p
     h->cfg.max_batch = nb;
     // the array keeps the previous call's (or chunk's) contents: the counters (the images' arrival
     // counters among them) start from zero
-    YP_HIP(hipMemsetAsync(h->s.seg_count, 0, L.n_cnt * sizeof(int32_t), st));
+    YP_HIP(hipMemsetAsync(h->s.lcount, 0, L.n_cnt * sizeof(int32_t), st));
     const int rcb = run_batch(h, nb, pred_offset + lo * A * 4, pred_cls + lo * A * C, pred_mask_coef + lo * A * YP_MASK_DIM, priors,
                               proto ? proto + lo * P * YP_MASK_DIM : nullptr, det_boxes + lo * R * 4, det_classes + lo * R,
                               det_scores + lo * R, det_masks ? det_masks + lo * R * P : nullptr,

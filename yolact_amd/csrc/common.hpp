@@ -3,7 +3,8 @@
 // Arithmetic contract "YP-MATH" (DESIGN.md section 3): every value the decisions of the
 // reference depend on (scores, decoded boxes, IoU) is computed with single IEEE f32
 // operations in the order the reference's Python expressions evaluate them, an explicit-fma
-// Cephes exp, a fixed softmax reduction tree and IEEE division.  All translation units are
+// Cephes exp, a fixed softmax reduction tree, one IEEE reciprocal per softmax row and IEEE
+// division elsewhere.  All translation units are
 // built with -ffp-contract=off; fma is only ever written explicitly.
 #pragma once
 
@@ -126,18 +127,30 @@ __device__ __forceinline__ void yp_sanitize(float a, float b, float img_size, bo
 #define YP_SF_TA 32   // anchors per score_filter tile (a multiple of 4, at most 32)
 #endif
 
+#define YP_NLISTS 16       // candidate lists per image: one per class group (per-class mode), or the image's
+                           // score_filter items dealt round-robin (cross-class mode)
+#define YP_CNT_STRIDE 32   // ints between two list counters: every counter has a 128-byte line of its own
+                           // (agent-scope atomics on one line are served one after the other, ~10 ns each:
+                           // tools/atomic_probe.hip)
+
 struct yp_scratch {
-  u64* cand;            // [nitems][cap_item] candidate keys: score_filter item i (image i / parts, part
-                        // i % parts) keeps seg_count[i] keys at the front of its list; unordered
-  int32_t* seg_count;   // [nitems] (rewritten every run)
-  int32_t* seg_surv;    // [nitems] anchors past the confidence filter (rewritten every run)
+  u64* lkeys;           // [batch][YP_NLISTS][lcap] candidate keys, appended by score_filter in no particular order
+  float4* lbox;         // [batch][YP_NLISTS][lcap] their decoded boxes (ymin,xmin,ymax,xmax pixels), same positions
+  int32_t* lcount;      // [max_batch][YP_NLISTS] x YP_CNT_STRIDE: entries appended (can exceed lcap: the excess went to
+                        // the overflow list); zero between launches - the NMS workgroup that reads a counter resets it
+  u64* okeys;           // [batch][ocap] per-class mode: keys that found their list full (no boxes); read by every class
+                        // group of the image
+  int32_t* ocount;      // [max_batch] x YP_CNT_STRIDE; zero between launches (reset by the image's final selection)
+  int32_t* seg_surv;    // [nitems] anchors past the confidence filter per score_filter item (rewritten every run)
   int32_t* stat_surv;   // [max_batch] anchors past the confidence filter, for yp_last_survivors
   u64* pool;            // [max_batch][ngroups][gcap] per-class NMS survivors (per-class mode), dense per class group
+  float4* pool_box;     // [max_batch][ngroups][gcap] their decoded boxes
   int32_t* pool_count;  // [max_batch][ngroups] (rewritten every run)
   int32_t* arrive;      // [max_batch] class groups of an image that have finished; zero between launches
-  int32_t* overflow;    // [1] set by score_filter when a work item had more keys than its list holds (yp_create_bounded)
+  int32_t* overflow;    // [1] set by score_filter when an image had more keys than its lists hold (yp_create_bounded)
   float4* crop;         // [max_batch][sel_rows] (x1,x2,y1,y2) crop edges in proto pixels
-  float* coef;          // [max_batch][sel_rows][32] coefficients of the kept detections
+  int32_t* sel_anchor;  // [max_batch][sel_rows] anchor of every kept detection: mask_assemble reads its coefficient
+                        // row straight from pred_mask_coef
 };
 
 // Experiment knobs, read from the environment ONCE, in yp_create (never on the launch path):
@@ -176,13 +189,12 @@ struct yp_handle {
   hipEvent_t ev[YP_NUM_KERNELS + 1];
 };
 
-// How score_filter cuts a batch into work items (and where the NMS kernels find their lists):
-// `parts` items per image, as many as keep every item resident at once, each a run of consecutive
-// tiles; an item's list holds at most cap_item keys.
+// How score_filter cuts a batch into work items: `parts` items per image, as many as keep every item
+// resident at once, each a run of consecutive tiles (`longest` tiles at most).
 // (Tried: shrinking the tile to 29 anchors so that 95 items x 7 tiles cover A = 19248 instead of
 // 86 x 7 x 32 with ten idle wave slots per image - 49.1 us against 48.0: more resident waves do not help
 // this kernel, and tiles that start off a 16-byte boundary cost more than the balance gains.)
-static inline void yp_plan_items(const yp_handle* h, int batch, int* parts, long long* cap_item) {
+static inline void yp_plan_items(const yp_handle* h, int batch, int* parts, int* longest_out) {
   const int ntiles = (h->cfg.num_anchors + YP_SF_TA - 1) / YP_SF_TA;
   const int resident = h->num_cus * h->sf_waves_per_cu;
   int pt = batch > 0 ? resident / batch : 1;
@@ -192,16 +204,47 @@ static inline void yp_plan_items(const yp_handle* h, int batch, int* parts, long
   const int longest = (ntiles + pt - 1) / pt;
   pt = (ntiles + longest - 1) / longest;
   *parts = pt;
-  *cap_item = (long long)longest * YP_SF_TA * h->keys_per_anchor;
+  *longest_out = longest;
 }
 
 // Per-class mode: the classes of an image are dealt round-robin to `ngroups` workgroups; a group's
 // pool list holds at most gcap keys (top_k per class).
 static inline void yp_plan_groups(const yp_handle* h, int* ngroups, int* gcap) {
-  const int ng = h->nseg < 16 ? h->nseg : 16;
+  const int ng = h->nseg < YP_NLISTS ? h->nseg : YP_NLISTS;
   *ngroups = ng;
   *gcap = ((h->nseg + ng - 1) / ng) * h->cfg.top_k;
 }
+
+// Where score_filter's candidates go: YP_NLISTS lists of lcap entries (key + box) per image, and - per-class
+// mode only - one overflow list of ocap keys per image for the keys that find their list full.
+//   cross-class  item `part` of an image appends to list part % YP_NLISTS; an anchor emits at most one key, so
+//                lcap = the anchors of the items that share a list: nothing can overflow
+//   per-class    list g takes the classes c with (c-1) % ngroups == g.  Its honest worst case is one key per
+//                (anchor, class of the group) - 37 MB per image at config 2 - so the lists are sized for what a
+//                class group can usefully hold (max(2048, A/8) entries, the whole worst case if that is less)
+//                and the overflow list for everything an image can emit (A * keys_per_anchor keys, the bound
+//                of yp_create / yp_create_bounded); a class group that finds overflow keys takes its slow path
+//                (nms.hip).  Only when the overflow list itself is full is a key dropped (bounded lists only).
+static inline void yp_plan_lists(const yp_handle* h, int batch, long long* lcap, long long* ocap) {
+  const long long A = h->cfg.num_anchors;
+  if (h->cfg.nms_mode == YP_NMS_CROSS_CLASS) {
+    int parts, longest;
+    yp_plan_items(h, batch, &parts, &longest);
+    long long c = (long long)((parts + YP_NLISTS - 1) / YP_NLISTS) * longest * YP_SF_TA;
+    *lcap = c < A ? c : A;
+    *ocap = 0;
+  } else {
+    int ng, gcap;
+    yp_plan_groups(h, &ng, &gcap);
+    long long kpl = (h->nseg + ng - 1) / ng;                       // classes per group
+    if (h->keys_per_anchor < kpl) kpl = h->keys_per_anchor;
+    const long long worst = A * kpl;
+    long long room = A / 8 > 2048 ? A / 8 : 2048;
+    *lcap = worst < room ? worst : room;
+    *ocap = A * h->keys_per_anchor;
+  }
+}
+
 
 int yp_score_filter_waves_per_cu(const yp_handle* h);
 
@@ -209,15 +252,15 @@ int yp_score_filter_waves_per_cu(const yp_handle* h);
 long long yp_priors_count(int num_levels, const int32_t* fmap_hw, int num_ratios);
 hipError_t yp_launch_make_priors(int img_h, int img_w, int num_levels, const int32_t* fmap_hw, const double* scales,
                                  int num_ratios, const double* sqrt_ratios, float* priors, hipStream_t st);
-hipError_t yp_launch_score_filter(const yp_handle* h, int batch, const float* pred_cls, hipStream_t st);
-hipError_t yp_launch_nms(const yp_handle* h, int batch, const float* pred_offset, const float* priors,
-                         const float* pred_mask_coef, float* det_boxes,
+hipError_t yp_launch_score_filter(const yp_handle* h, int batch, const float* pred_cls, const float* pred_offset,
+                                  const float* priors, hipStream_t st);
+hipError_t yp_launch_nms(const yp_handle* h, int batch, const float* pred_offset, const float* priors, float* det_boxes,
                          float* det_classes, float* det_scores, int32_t* num_det, int32_t* kept_idx,
                          float* fill_masks, uint8_t* fill_bitmaps, int fill_rows, hipStream_t st);
 int yp_mask_fill_rows(const yp_handle* h);
 int yp_mask_prefill(const yp_handle* h, int batch);
-hipError_t yp_launch_mask_assemble(const yp_handle* h, int batch, const float* proto, const int32_t* num_det,
-                                   float* det_masks, uint8_t* det_bitmaps, hipStream_t st);
+hipError_t yp_launch_mask_assemble(const yp_handle* h, int batch, const float* proto, const float* pred_mask_coef,
+                                   const int32_t* num_det, float* det_masks, uint8_t* det_bitmaps, hipStream_t st);
 hipError_t yp_launch_mask_rle(int batch, int max_dets, int ph, int pw, const float* det_masks, const int32_t* num_det,
                               int out_h, int out_w, float threshold, int order, uint8_t* bitmaps, uint32_t* counts,
                               int32_t* rle_len, int cap, hipStream_t st);

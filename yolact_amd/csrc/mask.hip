@@ -18,7 +18,10 @@
 
 struct MaskArgs {
   const float* proto;      // [B,P,32]
-  const float* coef;       // [B,sel_rows,32]
+  const float* coef;       // anchor != null: pred_mask_coef [B,A,32], row (b, anchor[b][n]) belongs to detection n;
+                           // anchor == null: [B,sel_rows,32], row (b, n)                       (detection.py:206)
+  const int32_t* anchor;   // [B,sel_rows] anchors of the kept detections (written by the NMS launch), or null
+  int A;
   const float4* crop;      // [B,sel_rows]  (x1,x2,y1,y2)
   const int32_t* num_det;  // [B]
   float* masks;            // [B,max_dets,P]
@@ -77,8 +80,9 @@ __global__ __launch_bounds__(YP_MASK_BLOCK) void mask_assemble_kernel(const Mask
   const int lane = t & 63;
   const int w0 = base_pix + __builtin_amdgcn_readfirstlane(t >> 6) * 64, w1 = min(w0 + 63, p.P - 1);
   u64 rel[NG];
+  int anch[NG];      // lane l: anchor of detection g*64 + l (same round trip as its crop edges)
 #pragma unroll
-  for (int g = 0; g < NG; ++g) rel[g] = 0ull;
+  for (int g = 0; g < NG; ++g) { rel[g] = 0ull; anch[g] = 0; }
   if (w0 < p.P) {
     const int r0 = w0 / p.pw, r1 = w1 / p.pw;
     int c0 = w0 - r0 * p.pw, c1 = w1 - r1 * p.pw;
@@ -89,6 +93,7 @@ __global__ __launch_bounds__(YP_MASK_BLOCK) void mask_assemble_kernel(const Mask
       if (g * 64 < N) {
         const int n = g * 64 + lane;
         const float4 cb = p.crop[(size_t)b * p.sel_rows + min(n, N - 1)];
+        if (p.anchor) anch[g] = p.anchor[(size_t)b * p.sel_rows + min(n, N - 1)];
         const bool hit = (n < N) && (fc1 >= cb.x) && (fc0 < cb.y) && (fr1 >= cb.z) && (fr0 < cb.w);
         const u64 m = __ballot(hit);
         rel[g] = ((u64)(uint32_t)__builtin_amdgcn_readfirstlane((int)(m >> 32)) << 32) |
@@ -131,7 +136,7 @@ __global__ __launch_bounds__(YP_MASK_BLOCK) void mask_assemble_kernel(const Mask
   uint8_t* brow = p.bitmaps ? p.bitmaps + ((size_t)b * p.max_dets) * p.P + base_pix : nullptr;
   typedef const __attribute__((address_space(4))) float cfloat;
   cfloat* const crop_c = (cfloat*)(p.crop + (size_t)b * p.sel_rows);
-  cfloat* const coef_c = (cfloat*)(p.coef + (size_t)b * p.sel_rows * YP_MASK_DIM);
+  cfloat* const coef_c = (cfloat*)(p.coef + (size_t)b * (p.anchor ? (size_t)p.A : (size_t)p.sel_rows) * YP_MASK_DIM);
 
   // The CU's scalar unit is shared by all its waves, and a loop over every detection with a test and
   // a branch per row is bound by it (measured: ~36 of 62 us with no memory traffic at all).  So only
@@ -187,7 +192,10 @@ __global__ __launch_bounds__(YP_MASK_BLOCK) void mask_assemble_kernel(const Mask
       // scalar cache) and never wait on this wave's own outstanding vector stores.
       float4 cb;
       cb.x = crop_c[4 * n + 0]; cb.y = crop_c[4 * n + 1]; cb.z = crop_c[4 * n + 2]; cb.w = crop_c[4 * n + 3];
-      cfloat* const cf = coef_c + n * YP_MASK_DIM;
+      // the detection's coefficient row: by its anchor, straight from pred_mask_coef (a wave-uniform index: the
+      // lane that tested detection n holds the anchor)
+      const int crow = p.anchor ? __builtin_amdgcn_readlane(anch[g], n & 63) : n;
+      cfloat* const cf = coef_c + (size_t)crow * YP_MASK_DIM;
       // mask_left & mask_right & mask_bottom & mask_top, float compares (utils/utils.py:125-130)
       const bool in = live && (fcol >= cb.x) && (fcol < cb.y) && (frow >= cb.z) && (frow < cb.w);
       if (__ballot(in) == 0ull) continue;      // the superset test let it through: the zeros stand
@@ -239,10 +247,11 @@ int yp_mask_fill_rows(const yp_handle* h) {
   return rows;
 }
 
-hipError_t yp_launch_mask_assemble(const yp_handle* h, int batch, const float* proto, const int32_t* num_det,
-                                   float* det_masks, uint8_t* det_bitmaps, hipStream_t st) {
+hipError_t yp_launch_mask_assemble(const yp_handle* h, int batch, const float* proto, const float* pred_mask_coef,
+                                   const int32_t* num_det, float* det_masks, uint8_t* det_bitmaps, hipStream_t st) {
   MaskArgs a;
-  a.proto = proto; a.coef = h->s.coef; a.crop = h->s.crop; a.num_det = num_det;
+  a.proto = proto; a.coef = pred_mask_coef; a.anchor = h->s.sel_anchor; a.A = h->cfg.num_anchors;
+  a.crop = h->s.crop; a.num_det = num_det;
   a.masks = det_masks; a.bitmaps = det_bitmaps;
   a.P = h->cfg.proto_h * h->cfg.proto_w; a.pw = h->cfg.proto_w;
   a.max_dets = h->cfg.max_dets; a.sel_rows = h->sel_rows; a.zero_pad = h->cfg.zero_pad_masks;
@@ -293,7 +302,8 @@ hipError_t yp_launch_loss_masks(int batch, int rows, int ph, int pw, int img_h, 
   const hipError_t e = yp_launch_crop_edges(batch * rows, ph, pw, img_h, img_w, use_crop, boxes, crop_ws, st);
   if (e != hipSuccess) return e;
   MaskArgs a;
-  a.proto = proto; a.coef = coef; a.crop = reinterpret_cast<const float4*>(crop_ws); a.num_det = num_rows;
+  a.proto = proto; a.coef = coef; a.anchor = nullptr; a.A = 0;
+  a.crop = reinterpret_cast<const float4*>(crop_ws); a.num_det = num_rows;
   a.masks = out_masks; a.bitmaps = nullptr;
   a.P = ph * pw; a.pw = pw; a.max_dets = rows; a.sel_rows = rows; a.zero_pad = 1; a.prezeroed = 0;
   a.mask_threshold = -1.0f;

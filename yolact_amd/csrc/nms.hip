@@ -12,8 +12,10 @@
 // workgroups wherever it is more than a few KB:
 //   cross-class  cc_nms_kernel: one workgroup per image (top_k <= 256 boxes reach the NMS)
 //   per-class    group_nms_kernel: 16 workgroups per image, each owning the classes c with
-//                (c-1) % 16 == g; all of a group's candidates are bucketed by class in LDS and
-//                ranked, decoded and suppressed thread-per-candidate;
+//                (c-1) % 16 == g; score_filter has already dealt the candidates - key + decoded box - to
+//                one list per group, so a group's workgroup loads its list length and its candidates in
+//                ONE round trip, keeps them in registers (up to 4 per thread), buckets the keys by class
+//                in LDS, ranks and suppresses thread-per-candidate;
 //                the group that finishes last (arrival counter, agent-scope release/acquire) then
 //                does the image's cross-class top max_dets selection and writes its output rows
 // Both kernels carry the zero-fill of the mask rows as extra workgroups behind the NMS workgroups
@@ -31,31 +33,33 @@
 #define YP_GSTAGE_CAP 2048   // the same for the per-class kernel's final selection (its LDS is kept small: the
                              // zero-fill workgroups of the same launch are allotted the same LDS and should fit 2 per CU
                              // beside 2 NMS workgroups)
-#define YP_GROUP_CAP 1024    // thread slots for the candidates of one class group (threads x YP_GROUP_KPT)
-#define YP_GROUP_LDS 768     // candidates of one class group that the thread-per-candidate path holds in LDS
-#define YP_GROUP_KEYS (2 * YP_GROUP_LDS)   // keys of a larger group that still stay in LDS for its class-by-class path
 #define YP_GROUP_THREADS 512
-#define YP_GROUP_KPT (YP_GROUP_CAP / YP_GROUP_THREADS)
+#define YP_GROUP_KPT 4       // candidates (key + box, in registers) a thread of a class group owns at most
+#define YP_GROUP_CAP (YP_GROUP_THREADS * YP_GROUP_KPT)   // candidates of one class group that take the thread-per-candidate path
+#define YP_GROUP_SORTED 1024 // ... if the top_k's of its classes add up to at most this many (boxes kept in LDS, sorted per class)
 
 struct NmsArgs {
-  const u64* cand;            // [B*parts][cap_item] score_filter's lists (common.hpp, yp_scratch)
-  const int32_t* seg_count;   // [B*parts] keys per list
-  const int32_t* seg_surv;    // [B*parts] anchors past the confidence filter per list
+  const u64* lkeys;           // [B][YP_NLISTS][lcap] score_filter's candidate lists (common.hpp, yp_scratch)
+  const float4* lbox;         // [B][YP_NLISTS][lcap] the candidates' decoded boxes
+  int32_t* lcount;            // [B][YP_NLISTS] x YP_CNT_STRIDE entries appended per list; reset here
+  const u64* okeys;           // [B][ocap] keys that found their list full (per-class mode)
+  int32_t* ocount;            // [B] x YP_CNT_STRIDE; reset here
+  const int32_t* seg_surv;    // [B*parts] anchors past the confidence filter per score_filter item
   int32_t* stat_surv;         // [B]
-  const float4* off;          // [B,A] pred_offset (dx,dy,dw,dh)
+  const float4* off;          // [B,A] pred_offset (dx,dy,dw,dh): only the slow paths decode from it
   const float4* priors;       // [A]   (ymin,xmin,ymax,xmax) pixels
   u64* pool;                  // [B,ngroups,gcap] per-class NMS survivors, final-key format, dense per group
+  float4* pool_box;           // [B,ngroups,gcap] their boxes
   int32_t* pool_count;        // [B,ngroups]
   float4* crop;               // [B,sel_rows]
-  float* coef_out;            // [B,sel_rows,32]
-  const float* coef_in;       // [B,A,32]
+  int32_t* sel_anchor;        // [B,sel_rows] anchors of the kept detections, for mask_assemble
   float* det_boxes;           // [B,max_dets,4]
   float* det_classes;         // [B,max_dets]
   float* det_scores;          // [B,max_dets]
   int32_t* num_det;           // [B]
   int32_t* kept_idx;          // [B,max_dets] (nullable)
   int A, nseg, top_k, max_dets, sel_rows, parts, ngroups, gcap;
-  long long cap_item;
+  long long lcap, ocap;
   // the mask zero-fill that rides in the same launch (workgroups with blockIdx.x >= nms_blocks)
   int32_t* arrive;            // [B] class groups of the image that have finished (per-class mode); zero between launches
   int nms_blocks;             // workgroups that do NMS work: B (cross-class) or B*ngroups (per-class)
@@ -92,7 +96,6 @@ struct SelectShared {
 // for_each visits every key once, spread over the workgroup's threads.  Loads are issued in
 // batches of independent loads so that one memory round trip serves a whole batch.
 #define YP_SRC_UNROLL 4
-#define YP_PART_UNROLL 8
 struct ListSrc {   // n contiguous keys (global or LDS)
   const u64* list;
   int n;
@@ -111,74 +114,77 @@ struct ListSrc {   // n contiguous keys (global or LDS)
     }
   }
 };
-struct PartSrc {   // score_filter's lists of one image: nparts lists of `cap` slots, list j holds counts[j] keys
-  const u64* base;
-  const int32_t* counts;
-  int nparts;
-  long long cap;
+// The keys of one class group of an image on its slow paths: the group's own list, then those of the image's
+// overflow keys (the keys that found their list full) that belong to the group - or, with cls > 0, of both
+// only the keys of that class.
+struct GroupSrc {
+  const u64* list;
+  int n;
+  const u64* ovf;
+  int novf;
   int cls;           // > 0: only the keys of this class
-  int gmod, grem;    // gmod > 0: only the keys of classes c with (c - 1) % gmod == grem
+  int gmod, grem;    // the group: classes c with (c - 1) % gmod == grem
   // (c - 1) % gmod without the integer division: for 0 <= x < 256 and gmod <= 256, (x + 0.5) / gmod is at
   // least 0.5 / gmod away from an integer, far more than the float error, so the truncation is x / gmod
-  __device__ __forceinline__ bool take(u64 k, float ginv) const {
+  __device__ __forceinline__ bool mine(u64 k, float ginv) const {
     const int c = yp_seg_key_class(k);
-    if (cls != 0 && c != cls) return false;
-    if (gmod == 0) return true;
+    if (cls != 0) return c == cls;
     const int q = (int)(((float)(c - 1) + 0.5f) * ginv);
     return (c - 1) - q * gmod == grem;
   }
   template <int THREADS, class F>
   __device__ __forceinline__ void for_each(F f) const {
-    int sft = 0;     // 1 << sft threads share a list: as many as the workgroup has to spare
-    while ((2 << sft) * nparts <= THREADS && sft < 6) ++sft;
-    const int lpp = 1 << sft;
-    const float ginv = 1.0f / (float)max(gmod, 1);
-    for (int s = threadIdx.x; s < (nparts << sft); s += THREADS) {
-      const int j = s >> sft, q = s & (lpp - 1);
-      const int n = counts[j];
-      const u64* l = base + (size_t)j * cap;
-      {
-        // first batch: issued without waiting for the count (slots past it hold stale keys, still
-        // inside the list's allocation), so count and keys share one round trip
-        u64 k[YP_PART_UNROLL];
+    const ListSrc own{list, n};
+    if (cls != 0) { const int c = cls; own.template for_each<THREADS>([&](u64 k) { if (yp_seg_key_class(k) == c) f(k); }); }
+    else own.template for_each<THREADS>(f);
+    if (novf > 0) {
+      const float ginv = 1.0f / (float)max(gmod, 1);
+      const ListSrc o{ovf, novf};
+      o.template for_each<THREADS>([&](u64 k) { if (mine(k, ginv)) f(k); });
+    }
+  }
+};
+// Cross-class mode: the image's YP_NLISTS lists, 64 threads (one wave) to a list.  The first YP_CC_PRE entries
+// per thread - keys and boxes - are loaded before the list lengths are known (slots past a list's end hold
+// stale entries, still inside its allocation), so that lengths, keys and boxes share ONE round trip.
+#define YP_CC_PRE 4
+#define YP_CC_THREADS 1024
+struct CcSrc {
+  const u64* keys;        // the image's lists
+  const float4* boxes;
+  long long lcap;
+  const int* cnt;         // LDS: entries per list (already cut to lcap)
+  u64 pre[YP_CC_PRE];     // this thread's first YP_CC_PRE keys (a member, not a pointer: it stays in registers)
+  template <int THREADS, class F>
+  __device__ __forceinline__ void for_each(F f) const {
+    static_assert(THREADS == YP_NLISTS * YP_WAVE, "one wave per list");
+    const int l = threadIdx.x >> 6, q = threadIdx.x & 63;
+    const int n = cnt[l];
+    const u64* list = keys + (size_t)l * lcap;
 #pragma unroll
-        for (int u = 0; u < YP_PART_UNROLL; ++u) k[u] = l[min((long long)(q + u * lpp), cap - 1)];
+    for (int u = 0; u < YP_CC_PRE; ++u)
+      if (q + u * YP_WAVE < n) f(pre[u]);
+    for (int i0 = q + YP_WAVE * YP_CC_PRE; i0 < n; i0 += YP_WAVE * YP_SRC_UNROLL) {
+      u64 k[YP_SRC_UNROLL];
 #pragma unroll
-        for (int u = 0; u < YP_PART_UNROLL; ++u)
-          if (q + u * lpp < n && take(k[u], ginv)) f(k[u]);
-      }
-      for (int i0 = q + lpp * YP_PART_UNROLL; i0 < n; i0 += lpp * YP_PART_UNROLL) {
-        u64 k[YP_PART_UNROLL];
+      for (int u = 0; u < YP_SRC_UNROLL; ++u) k[u] = list[min(i0 + u * YP_WAVE, n - 1)];
 #pragma unroll
-        for (int u = 0; u < YP_PART_UNROLL; ++u) k[u] = l[min(i0 + u * lpp, n - 1)];
-#pragma unroll
-        for (int u = 0; u < YP_PART_UNROLL; ++u)
-          if (i0 + u * lpp < n && take(k[u], ginv)) f(k[u]);
-      }
+      for (int u = 0; u < YP_SRC_UNROLL; ++u)
+        if (i0 + u * YP_WAVE < n) f(k[u]);
     }
   }
 };
 #define YP_POOL_PRE 8   // keys per thread of PoolSrc's first batch, loaded before the list lengths are known
+#define YP_POOL_PRE_BOX 4   // ... of which this many come with their boxes (enough for max_dets <= 128 with 16 groups)
 struct PoolSrc {   // ngroups lists of gcap slots; list g holds its keys at [0, start[g+1] - start[g])
   const u64* base;
   const int* start;   // LDS: exclusive prefix of the list lengths, ngroups + 1 entries
   int ngroups, gcap;
-  const u64* pre;     // this thread's first YP_POOL_PRE keys (registers), loaded by preload()
+  u64 pre[YP_POOL_PRE];   // this thread's first YP_POOL_PRE keys (a member, not a pointer: it stays in registers)
   __device__ __forceinline__ int shift() const {
     int sft = 0;      // 1 << sft threads share a list
     while ((2 << sft) * ngroups <= (int)blockDim.x && sft < 6) ++sft;
     return sft;
-  }
-  // The first batch of every list, issued WITHOUT waiting for the lengths (slots past a list's end hold
-  // stale keys, still inside its allocation), so that lengths and keys share one round trip.  Needs
-  // ngroups << shift() <= blockDim.x (16 groups: always).
-  __device__ __forceinline__ void preload(u64* k) const {
-    const int sft = shift(), lpp = 1 << sft;
-    const int s = min((int)threadIdx.x, (ngroups << sft) - 1);
-    const int g = s >> sft, q = s & (lpp - 1);
-    const u64* l = base + (size_t)g * gcap;
-#pragma unroll
-    for (int u = 0; u < YP_POOL_PRE; ++u) k[u] = l[min(q + u * lpp, gcap - 1)];
   }
   template <int THREADS, class F>
   __device__ __forceinline__ void for_each(F f) const {
@@ -495,15 +501,79 @@ __device__ __forceinline__ void pair_sweep(const float4* box, T* sup, int k, flo
   }
 }
 
+// ---- the sweep of a LARGE class: cell masks first, the IoU arithmetic only where two boxes can meet ---------------
+// Pair tests are what a saturated image costs (config 4: 80 classes x 19 900 pairs x 32 images = 51 M per batch at
+// ~45 vector instructions each: the class groups were vector-ALU bound, 59 us of their 110).  Almost all of those
+// pairs are boxes that do not intersect at all, and a pair with inter == 0 can never exceed the threshold
+// (utils/utils.py:68-70, thr > 0).  So every box gets a 64-bit mask of the cells of an 8 x 8 grid over the image
+// that it touches; two boxes that intersect share a cell (the cell index is a monotone function of the
+// coordinate, and max(xmin_a, xmin_b) lies in both boxes' ranges), so `mask_i & mask_j == 0` proves inter == 0
+// exactly.  A wave takes four columns at a time, its lanes 64 rows: one LDS read and ~5 vector instructions per
+// 64 pairs and column.  The pairs that pass (a few per cent) are queued per wave in LDS and get the full test
+// (yp_iou_gt, the reference's arithmetic) 64 at a time, one pair per lane.
+__device__ __forceinline__ u64 yp_cell_mask(const float4 bx /* ymin,xmin,ymax,xmax */, float sx, float sy) {
+  // cell = clamp(trunc(coordinate * 8 / size), 0, 7): monotone; NaN goes to 0
+  const int cx0 = (int)fminf(fmaxf(bx.y * sx, 0.0f), 7.0f), cx1 = (int)fminf(fmaxf(bx.w * sx, 0.0f), 7.0f);
+  const int cy0 = (int)fminf(fmaxf(bx.x * sy, 0.0f), 7.0f), cy1 = (int)fminf(fmaxf(bx.z * sy, 0.0f), 7.0f);
+  const uint32_t cols = ((2u << max(cx0, cx1)) - (1u << min(cx0, cx1))) & 0xffu;   // bits cx0..cx1
+  const uint32_t rows = ((2u << max(cy0, cy1)) - (1u << min(cy0, cy1))) & 0xffu;   // bits cy0..cy1
+  // every row bit becomes a byte holding `cols` (cols < 256: no carries between the bytes)
+  const uint32_t rl = rows & 0xfu, rh = rows >> 4;
+  const uint32_t lo = cols * ((rl & 1u) | ((rl & 2u) << 7) | ((rl & 4u) << 14) | ((rl & 8u) << 21));
+  const uint32_t hi = cols * ((rh & 1u) | ((rh & 2u) << 7) | ((rh & 4u) << 14) | ((rh & 8u) << 21));
+  return ((u64)hi << 32) | lo;
+}
+
+#define YP_SWEEP_COLS 4     // columns a wave tests per pass over the rows
+#define YP_SWEEP_QUEUE 128  // pair-queue entries per wave (a drain leaves < 64, a column adds <= 64)
+template <class T>
+__device__ __forceinline__ void pair_sweep_cells(const float4* box, const u64* cmask, T* sup, uint32_t* queue /* this wave's */,
+                                                 int k, float thr, int wave, int nw, int lane) {
+  int qlen = 0;                                                 // wave-uniform
+  const u64 lt = (1ull << lane) - 1ull;
+  auto drain = [&](int n) {                                     // the first n (<= 64) queued pairs get the full test
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t pr = queue[min(lane, n - 1)];
+    const int i = (int)(pr & 0xffffu), j = (int)(pr >> 16);
+    const bool hit = yp_iou_gt(box[i], box[j], thr);           // box i outranks box j (detection.py:190-202)
+    if (lane < n && hit) sup[j] = 1;
+    const int rest = qlen - n;                                  // < 64
+    const uint32_t mv = queue[min(n + lane, YP_SWEEP_QUEUE - 1)];
+    __builtin_amdgcn_wave_barrier();
+    if (lane < rest) queue[lane] = mv;
+    qlen = rest;
+  };
+  const int w = __builtin_amdgcn_readfirstlane(wave);
+  for (int j0 = 1 + w * YP_SWEEP_COLS; j0 < k; j0 += nw * YP_SWEEP_COLS) {     // (column 0 has no rows)
+    u64 mj[YP_SWEEP_COLS];
+#pragma unroll
+    for (int c = 0; c < YP_SWEEP_COLS; ++c) mj[c] = cmask[min(j0 + c, k - 1)];   // broadcasts
+    const int jl = min(j0 + YP_SWEEP_COLS - 1, k - 1);         // the pass's last column: rows 0 .. jl-1
+    for (int i0 = 0; i0 < jl; i0 += YP_WAVE) {
+      const int i = i0 + lane;
+      const u64 mi = cmask[min(i, jl - 1)];
+#pragma unroll
+      for (int c = 0; c < YP_SWEEP_COLS; ++c) {
+        const int j = j0 + c;
+        const bool pass = (i < j) && (j < k) && ((mi & mj[c]) != 0ull);
+        const u64 bm = __ballot(pass);
+        if (bm != 0ull) {                                       // (wave-uniform)
+          if (pass) queue[qlen + __popcll(bm & lt)] = (uint32_t)i | ((uint32_t)j << 16);
+          qlen += __popcll(bm);
+          if (qlen >= YP_WAVE) drain(YP_WAVE);
+        }
+      }
+    }
+  }
+  if (qlen > 0) drain(qlen);
+}
+
 // Output row r of image b: sanitize + normalise (detection.py:92-98), class/score/index
 // (L110-112), the row's crop edges (utils/utils.py:116-117 with padding 1.0, normalised
-// coordinates: SURVEY.md A12) and its coefficient row, compacted for mask_assemble (L206).
-// `of`/`pr` are the anchor's offsets and prior, `cf` its 8 x float4 coefficient row: the caller
-// loads them together, in one round trip.
-struct CoefRow { float4 q0, q1, q2, q3, q4, q5, q6, q7; };   // named members: stays in VGPRs (an indexed array went to scratch)
-static_assert(YP_MASK_DIM == 32, "CoefRow holds 32 coefficients");
+// coordinates: SURVEY.md A12) and its anchor, from which mask_assemble finds the coefficient row.
+// `bx` is the decoded box as score_filter stored it beside the key.
 __device__ __forceinline__ void emit_row(const NmsArgs& p, int b, int r, float score, int cls, int anchor,
-                                         const float4 bx /* ymin,xmin,ymax,xmax pixels */, const CoefRow& cf) {
+                                         const float4 bx /* ymin,xmin,ymax,xmax pixels */) {
   float x1, x2, y1, y2;
   yp_sanitize(bx.y, bx.w, p.img_w, false, 0.0f, x1, x2);     // detection.py:126
   yp_sanitize(bx.x, bx.z, p.img_h, false, 0.0f, y1, y2);     // detection.py:127
@@ -522,12 +592,17 @@ __device__ __forceinline__ void emit_row(const NmsArgs& p, int b, int r, float s
     cb.x = 0.0f; cb.y = p.proto_w; cb.z = 0.0f; cb.w = p.proto_h;
   }
   p.crop[(size_t)b * p.sel_rows + r] = cb;
-  float4* co = reinterpret_cast<float4*>(p.coef_out + ((size_t)b * p.sel_rows + r) * YP_MASK_DIM);
-  co[0] = cf.q0; co[1] = cf.q1; co[2] = cf.q2; co[3] = cf.q3; co[4] = cf.q4; co[5] = cf.q5; co[6] = cf.q6; co[7] = cf.q7;
+  p.sel_anchor[(size_t)b * p.sel_rows + r] = anchor;         // mask_assemble reads the coefficient row itself (L206)
 }
-__device__ __forceinline__ void load_coef(const NmsArgs& p, int b, int anchor, CoefRow& cf) {
-  const float4* ci = reinterpret_cast<const float4*>(p.coef_in + ((size_t)b * p.A + anchor) * YP_MASK_DIM);
-  cf.q0 = ci[0]; cf.q1 = ci[1]; cf.q2 = ci[2]; cf.q3 = ci[3]; cf.q4 = ci[4]; cf.q5 = ci[5]; cf.q6 = ci[6]; cf.q7 = ci[7];
+
+// Position of `key` in k unique keys sorted descending (it is one of them).
+__device__ __forceinline__ int rank_desc(const u64* sorted, int k, u64 key) {
+  int lo = 0, hi = k - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (sorted[mid] > key) lo = mid + 1; else hi = mid;
+  }
+  return lo;
 }
 
 // Rows [n, max_dets) of image b: zeros / -1 (detection.py:65-67); num_det (L114).
@@ -634,6 +709,9 @@ __device__ __forceinline__ void fill_block(const NmsArgs& p, long long ch) {
 }
 
 // Cross-class mode: one workgroup per image (detection.py:181-209).
+// One round trip brings the lengths of the image's lists and the first YP_CC_PRE entries per thread (keys and
+// boxes, 4096 per image); the top_k selection runs on the keys; then every thread that holds one of the selected
+// keys drops its box at the key's rank.  No gather from pred_offset, no coefficient copy.
 template <int THREADS>
 __global__ __launch_bounds__(THREADS) void cc_nms_kernel(const NmsArgs p) {
   __shared__ SelectShared sh;
@@ -642,6 +720,7 @@ __global__ __launch_bounds__(THREADS) void cc_nms_kernel(const NmsArgs p) {
   __shared__ float4 sbox[YP_SORT_MAX];
   __shared__ int ssup[YP_SORT_MAX];
   __shared__ int s_wave_cnt[YP_SORT_MAX / YP_WAVE];
+  __shared__ int s_cnt[YP_NLISTS];
   const int t = threadIdx.x;
   if ((int)blockIdx.x >= p.nms_blocks) {   // workgroup-uniform
     fill_block<THREADS>(p, (long long)blockIdx.x - p.nms_blocks);
@@ -651,33 +730,54 @@ __global__ __launch_bounds__(THREADS) void cc_nms_kernel(const NmsArgs p) {
   const int b = blockIdx.x;
   STAMP_INIT(0, b);
   STAMP(0);
-  const int32_t* counts = p.seg_count + (size_t)b * p.parts;
+  const int l = t >> 6, q = t & 63;        // wave l reads list l
+  const u64* const lk = p.lkeys + ((size_t)b * YP_NLISTS) * p.lcap;
+  const float4* const lb = p.lbox + ((size_t)b * YP_NLISTS) * p.lcap;
+  int32_t* const cnt_g = p.lcount + ((size_t)b * YP_NLISTS) * YP_CNT_STRIDE;
+  int my_cnt = 0;
+  if (q == 0) my_cnt = cnt_g[l * YP_CNT_STRIDE];
+  CcSrc src{lk, lb, p.lcap, s_cnt, {}};
+  float4 preb[YP_CC_PRE];
+#pragma unroll
+  for (int u = 0; u < YP_CC_PRE; ++u) {
+    const size_t o = (size_t)l * p.lcap + min((long long)(q + u * YP_WAVE), p.lcap - 1);
+    src.pre[u] = lk[o];
+    preb[u] = lb[o];
+  }
   int part = 0;
-  for (int i = t; i < p.parts; i += THREADS) part += counts[i];
-  const int n = block_sum<THREADS>(part, sh.wtot);            // survivors of the confidence filter
+  for (int i = t; i < p.parts; i += THREADS) part += p.seg_surv[(size_t)b * p.parts + i];
+  if (q == 0) {
+    my_cnt = (int)min((long long)my_cnt, p.lcap);   // (an anchor emits one key: the lists cannot overflow)
+    s_cnt[l] = my_cnt;
+    if (my_cnt != 0) cnt_g[l * YP_CNT_STRIDE] = 0;  // ready for the next launch: this workgroup is the counter's only reader
+  }
+  const int survivors = block_sum<THREADS>(part, sh.wtot);    // (its barriers also publish s_cnt[])
+  int n = 0;
+#pragma unroll
+  for (int i = 0; i < YP_NLISTS; ++i) n += s_cnt[i];          // candidates of the image
   if (n == 0) {                                                // detection.py:81
-    finish_image<THREADS>(p, b, 0, 0);
+    finish_image<THREADS>(p, b, 0, survivors);
     return;
   }
   STAMP(1);
-  const PartSrc src{p.cand + (size_t)b * p.parts * p.cap_item, counts, p.parts, p.cap_item, 0, 0, 0};
 #ifdef YP_STAMPS
   const int k = select_topk_sorted<THREADS>(src, n, p.top_k, sh, stage, YP_STAGE_CAP, dbg_);
 #else
   const int k = select_topk_sorted<THREADS>(src, n, p.top_k, sh, stage, YP_STAGE_CAP);       // detection.py:186
 #endif
   STAMP(2);
-  float4 mybox = make_float4(0.f, 0.f, 0.f, 0.f);
-  CoefRow cf = {};
-  int anchor = 0;
-  if (t < YP_SORT_MAX) {
-    ssup[t] = 0;
-    if (t < k) {                                                                        // L187, L79
-      anchor = min(yp_seg_key_anchor(sh.key[t]), p.A - 1);   // (clamp: never index out of bounds)
-      const float4 pr = p.priors[anchor], of = p.off[(size_t)b * p.A + anchor];
-      load_coef(p, b, anchor, cf);   // same round trip; only the kept rows are stored
-      mybox = yp_decode(pr, of);
-      sbox[t] = mybox;
+  if (t < YP_SORT_MAX) ssup[t] = 0;
+  {
+    // the selected keys' boxes (detection.py:187, :79): whoever holds a key >= the k-th largest puts its box at
+    // the key's rank
+    const u64 kth = sh.key[k - 1];
+    const int nl = s_cnt[l];
+#pragma unroll
+    for (int u = 0; u < YP_CC_PRE; ++u)
+      if (q + u * YP_WAVE < nl && src.pre[u] >= kth) sbox[rank_desc(sh.key, k, src.pre[u])] = preb[u];
+    for (int i = q + YP_WAVE * YP_CC_PRE; i < nl; i += YP_WAVE) {   // (lists longer than the first batch: rare)
+      const u64 key = lk[(size_t)l * p.lcap + i];
+      if (key >= kth) sbox[rank_desc(sh.key, k, key)] = lb[(size_t)l * p.lcap + i];
     }
   }
   __syncthreads();
@@ -688,10 +788,10 @@ __global__ __launch_bounds__(THREADS) void cc_nms_kernel(const NmsArgs p) {
   const int nk = min(total, p.max_dets);
   if (keep && pos < nk) {
     const u64 key = sh.key[t];
-    emit_row(p, b, pos, yp_key_score(key), yp_seg_key_class(key), anchor, mybox, cf);   // detection.py:204-207
+    emit_row(p, b, pos, yp_key_score(key), yp_seg_key_class(key), min(yp_seg_key_anchor(key), p.A - 1), sbox[t]);   // detection.py:204-207
   }
   STAMP(5);
-  finish_image<THREADS>(p, b, nk, n);
+  finish_image<THREADS>(p, b, nk, survivors);
   STAMP(6);
 }
 
@@ -701,64 +801,57 @@ __global__ __launch_bounds__(THREADS) void cc_nms_kernel(const NmsArgs p) {
 // that the hand-off needs no agent-scope release - a release writes back every dirty line of the
 // XCD's L2, and with the mask zero-fill running in the same launch that is megabytes per fence
 // (measured: 208 us per launch with release fences against ~50 with write-through stores).
+// tests/test_abi.py disassembles the built library and checks that these stores carry sc1.
 __device__ __forceinline__ void store_wt(u64* p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void store_wt(int32_t* p, int32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void store_wt(float4* p, const float4 v) {
+  u64* const q = reinterpret_cast<u64*>(p);
+  store_wt(q, ((u64)__builtin_bit_cast(uint32_t, v.y) << 32) | __builtin_bit_cast(uint32_t, v.x));
+  store_wt(q + 1, ((u64)__builtin_bit_cast(uint32_t, v.w) << 32) | __builtin_bit_cast(uint32_t, v.z));
+}
 
 struct GroupShared {
-  // One 24 KiB region with two lives.  During the group's own NMS: a | bk | box.  During a select (the
-  // class-by-class fallback of a large group, and the image's final selection by the last group):
-  // stage | hist, with the fallback's <= 256 sorted boxes in the first 4 KiB of `box`, which neither covers.
+  // One 24 KiB region with several lives.
+  //   thread-per-candidate path:  bk (keys bucketed by class, while they are ranked), then box (per class the
+  //                               top_k boxes in rank order, while they are swept), then stage|hist for the cut
+  //                               of the pooled survivors to the group's best max_dets;
+  //   class-by-class slow path:   box[0..256) = the class's sorted boxes, hist behind them;
+  //   the image's final selection (last group): stage | hist.
   union {
+    u64 bk[YP_GROUP_CAP];
     struct {
-      u64 a[YP_GROUP_LDS];          // the group's keys as they arrive; later, per class, the top_k keys in descending order
-      u64 bk[YP_GROUP_LDS];         // keys bucketed by class; later the pooled NMS survivors (final-key format)
-      float4 box[YP_GROUP_LDS];     // decoded boxes, at the positions of `a`
-    };
-    struct {
-      u64 stage[YP_GSTAGE_CAP];     // final selection: the image's pooled survivors
+      u64 stage[YP_GSTAGE_CAP];     // a select's staged keys
       int hist[YP_RADIX_BINS];      // radix histogram of a select
     };
+    struct {
+      float4 box[YP_GROUP_SORTED];
+      u64 cmask[YP_GROUP_SORTED];   // the cells of an 8 x 8 grid over the image that a box touches (sweeps of large classes)
+    };
   };
-  unsigned char pcls[YP_GROUP_LDS];   // class of every bucket position
-  unsigned char psup[YP_GROUP_LDS];   // 1 = suppressed by a higher-ranked box of its class
+  unsigned char psup[YP_GROUP_SORTED];   // 1 = suppressed by a higher-ranked box of its class (sorted positions)
   SelectShared sh;
-  int cls_cnt[256], cls_off[256], cls_fill[256];
+  int cls_cnt[256], cls_off[256], cls_fill[256], cls_soff[256];
   int ssup[YP_SORT_MAX];
   int s_wave_cnt[YP_SORT_MAX / YP_WAVE];
   int start[32];                // final selection: exclusive prefix of the groups' pool lengths
-  int fill, npool, last;
+  int nsorted, npool, last, m_raw, novf_raw;
 };
-static_assert(YP_GSTAGE_CAP * sizeof(u64) + YP_RADIX_BINS * sizeof(int) <= 2 * YP_GROUP_LDS * sizeof(u64) + YP_GROUP_LDS * sizeof(float4),
-              "stage | hist alias a | bk | box");
-static_assert(YP_GSTAGE_CAP * sizeof(u64) >= 2 * YP_GROUP_LDS * sizeof(u64) + YP_SORT_MAX * sizeof(float4),
-              "hist starts behind the fallback's sorted boxes (box[0..256))");
+static_assert(YP_GROUP_CAP * sizeof(u64) <= YP_GSTAGE_CAP * sizeof(u64) && YP_GROUP_CAP <= YP_RADIX_BINS, "bk lies before hist, whose words hold the candidates' ranks");
+static_assert(YP_GROUP_SORTED * sizeof(float4) == YP_GSTAGE_CAP * sizeof(u64) && YP_GROUP_SORTED * sizeof(u64) <= YP_RADIX_BINS * sizeof(int),
+              "hist lies behind box[] (and behind the slow path's box[0..256)); cmask[] lies over hist");
+static_assert((YP_GROUP_THREADS / YP_WAVE) * YP_SWEEP_QUEUE * sizeof(uint32_t) <= 2 * YP_SORT_MAX * sizeof(u64),
+              "the waves' pair queues fit SelectShared's key | tmp (idle during the sweeps)");
+static_assert(YP_GROUP_SORTED * sizeof(u64) <= YP_GSTAGE_CAP * sizeof(u64), "the pooled keys of the cut fit the stage");
 
-// Top_k + Fast NMS of ONE class with the whole workgroup (any number of candidates): the path for
-// groups too large for the thread-per-candidate code.  Appends the survivors to pool[base...] and
+// Top_k + Fast NMS of ONE class with the whole workgroup (any number of candidates): the slow path, for
+// groups the thread-per-candidate code cannot take.  Appends the survivors to pool[base...] and
 // returns their number.  All threads must call it.
-struct LdsClassSrc {   // the keys of one class among n keys that sit in LDS
-  const u64* keys;
-  int n, cls;
-  template <int THREADS, class F>
-  __device__ __forceinline__ void for_each(F f) const {
-    for (int i = threadIdx.x; i < n; i += THREADS) {
-      const u64 k = keys[i];
-      if (yp_seg_key_class(k) == cls) f(k);
-    }
-  }
-};
-
-template <int THREADS, class SRC>
-__device__ __forceinline__ int class_nms_blockwide(const NmsArgs& p, int b, int cls, const SRC& src, GroupShared& gs, u64* pool, int base) {
+template <int THREADS>
+__device__ __forceinline__ int class_nms_blockwide(const NmsArgs& p, int b, int cls, const GroupSrc& src, GroupShared& gs, u64* pool,
+                                                   float4* pbox, int base) {
   const int t = threadIdx.x;
   SelectShared& sh = gs.sh;
   float4* sbox = gs.box;
-#ifdef YP_STAMPS   // stamps 2..6 of the group's row: its FIRST class
-  unsigned long long* const dbg_ = p.dbg + (size_t)(b * p.ngroups + (cls - 1) % p.ngroups) * 16;
-#define CSTAMP(i) do { if (cls <= p.ngroups) STAMP(i); } while (0)
-#else
-#define CSTAMP(i)
-#endif
   __syncthreads();
   if (t == 0) sh.fill = 0;
   if (t < YP_SORT_MAX) { gs.ssup[t] = 0; sh.rank[t] = 0; }
@@ -770,7 +863,6 @@ __device__ __forceinline__ int class_nms_blockwide(const NmsArgs& p, int b, int 
   __syncthreads();
   const int n = sh.fill;
   if (n == 0) return 0;
-  CSTAMP(2);
   int k;
   if (n <= YP_SORT_MAX) {
     rank_sort_desc<THREADS>(sh, n);
@@ -779,143 +871,217 @@ __device__ __forceinline__ int class_nms_blockwide(const NmsArgs& p, int b, int 
     __syncthreads();   // everybody has read sh.fill
     k = select_topk_sorted<THREADS>(src, n, p.top_k, sh, nullptr, 0);             // detection.py:217
   }
-  CSTAMP(3);
+  float4 mybox = make_float4(0.f, 0.f, 0.f, 0.f);
   if (t < k) {                                                                          // detection.py:219
     const int a = min(yp_seg_key_anchor(sh.key[t]), p.A - 1);   // (clamp: never index out of bounds)
-    sbox[t] = yp_decode(p.priors[a], p.off[(size_t)b * p.A + a]);
+    mybox = yp_decode(p.priors[a], p.off[(size_t)b * p.A + a]);
+    sbox[t] = mybox;
   }
   __syncthreads();
-  CSTAMP(4);
   int pos, total;
   const bool keep = fast_nms_keep<THREADS>(sbox, gs.ssup, gs.s_wave_cnt, k, p.nms_thresh, pos, total);
-  CSTAMP(5);
   if (keep) {                                                                           // detection.py:234-239
     const u64 key = sh.key[t];
     store_wt(&pool[base + pos], yp_fin_key(yp_key_score(key), yp_seg_key_anchor(key), cls));
+    store_wt(&pbox[base + pos], mybox);
   }
-  CSTAMP(6);
   return total;
+}
+
+// Slow path of a class group: class by class, each with the whole workgroup, streaming the group's list (and the
+// image's overflow keys) from memory for every class and decoding the boxes from the inputs.  Taken when the
+// group has more candidates than the thread-per-candidate path holds, or when the image has overflow keys.
+template <int THREADS>
+__device__ __forceinline__ void group_nms_slow(const NmsArgs& p, int b, int g, int m, int novf, GroupShared& gs, u64* pool, float4* pbox) {
+  const int t = threadIdx.x;
+  const size_t li = (size_t)b * YP_NLISTS + g;
+  int base = 0;
+  for (int c = g + 1; c <= p.nseg; c += p.ngroups) {
+    const GroupSrc csrc{p.lkeys + li * p.lcap, m, p.okeys + (size_t)b * p.ocap, novf, c, p.ngroups, g};
+    base += class_nms_blockwide<THREADS>(p, b, c, csrc, gs, pool, pbox, base);
+  }
+  const int want = min(p.max_dets, YP_SORT_MAX);
+  if (base > want) {
+    // cut the pooled list to the group's best max_dets (see group_nms_body, step 6): read back from L2, where the
+    // write-through stores of all waves are once they have drained
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    const ListSrc ls{pool, base};
+    const int kept = select_topk_sorted<THREADS>(ls, base, want, gs.sh, gs.stage, YP_GSTAGE_CAP);
+    // the boxes of the kept keys, moved to the keys' new places: read all first, then write
+    float4 bx = make_float4(0.f, 0.f, 0.f, 0.f);
+    int dst = -1;
+    const u64 kth = gs.sh.key[kept - 1];
+    // (base <= nclasses * top_k can exceed the thread count: the old slots are visited in rounds of THREADS.
+    //  Every new place is a rank < kept <= 256 <= THREADS, i.e. inside the FIRST round's range, whose reads all
+    //  complete before its writes; later rounds read slots that no round writes.)
+    for (int i0 = 0; i0 < base; i0 += THREADS) {
+      const int i = i0 + t;
+      dst = -1;
+      if (i < base) {
+        const u64 key = pool[i];
+        if (key >= kth) { dst = rank_desc(gs.sh.key, kept, key); bx = pbox[i]; }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (dst >= 0) { store_wt(&pool[dst], gs.sh.key[dst]); store_wt(&pbox[dst], bx); }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+    base = kept;
+  }
+  if (t == 0) store_wt(&p.pool_count[(size_t)b * p.ngroups + g], base);
 }
 
 // Workgroup (g, b): the classes c of image b with (c-1) % ngroups == g (detection.py:217-239).
 template <int THREADS>
 __device__ __forceinline__ void group_nms_body(const NmsArgs& p, int b, int g, GroupShared& gs) {
-  static_assert(THREADS * YP_GROUP_KPT >= YP_GROUP_LDS, "every candidate needs a thread slot");
+  constexpr int KPT = YP_GROUP_KPT;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const size_t li = (size_t)b * YP_NLISTS + g;
+  const u64* const lk = p.lkeys + li * p.lcap;
+  const float4* const lb = p.lbox + li * p.lcap;
   u64* const pool = p.pool + ((size_t)b * p.ngroups + g) * p.gcap;
+  float4* const pbox = p.pool_box + ((size_t)b * p.ngroups + g) * p.gcap;
   STAMP_INIT(0, b * p.ngroups + g);
   STAMP(0);
-  // 1. one pass over the image's lists (a few tens of KB, shared by the image's workgroups through
-  //    L2): this group's keys into LDS, class histogram on the way
-  if (t < 256) { gs.cls_cnt[t] = 0; gs.cls_fill[t] = 0; }
-  if (t == 0) { gs.fill = 0; gs.npool = 0; gs.sh.hist = gs.hist; }
+  // 1. ONE round trip: the list's length, the image's overflow count and the first THREADS candidates - key
+  //    and box - loaded before the length is known (slots past the list's end hold stale entries, still inside
+  //    the allocation)
+  //    ONE thread reads the counters and resets the list's for the next launch (this workgroup is that counter's
+  //    only reader; a reset by thread 0 while other waves still load the counter themselves would hand them a 0);
+  //    everybody else gets the values through LDS.
+  if (t == 0) {
+    const int c = p.lcount[li * YP_CNT_STRIDE];
+    const int o = p.ocount[(size_t)b * YP_CNT_STRIDE];
+    gs.m_raw = c;
+    gs.novf_raw = o;
+    if (c != 0) p.lcount[li * YP_CNT_STRIDE] = 0;
+  }
+  u64 key[KPT];
+  float4 box[KPT];
+  {
+    const long long i = min((long long)t, p.lcap - 1);
+    key[0] = lk[i];
+    box[0] = lb[i];
+  }
+  if (t < 256) { gs.cls_cnt[t] = 0; gs.cls_fill[t] = 0; reinterpret_cast<int*>(gs.psup)[t] = 0; }
+  if (t == 0) { gs.npool = 0; gs.sh.hist = gs.hist; }
   __syncthreads();
-  const PartSrc src{p.cand + (size_t)b * p.parts * p.cap_item, p.seg_count + (size_t)b * p.parts, p.parts, p.cap_item, 0, p.ngroups, g};
-  src.template for_each<THREADS>([&](u64 key) {
-    const int q = lds_append_slot(&gs.fill);
-    if (q < YP_GROUP_KEYS) gs.a[q] = key;   // (a and bk are one array of YP_GROUP_KEYS keys here)
-    atomicAdd(&gs.cls_cnt[yp_seg_key_class(key)], 1);
-  });
-  __syncthreads();
-  const int m = gs.fill;
+  const int m = (int)min((long long)gs.m_raw, p.lcap);            // (workgroup-uniform)
+  const int novf = (int)min((long long)gs.novf_raw, p.ocap);
   STAMP(1);
-  if (m == 0) {
+  if (m == 0 && novf == 0) {
     if (t == 0) store_wt(&p.pool_count[(size_t)b * p.ngroups + g], 0);
     return;
   }
-  if (m > YP_GROUP_LDS) {
-    // too many for a thread per candidate: class by class, each with the whole workgroup; from the keys in
-    // LDS while they fit (a | bk as one array; the sorted boxes and a select's histogram lie behind them),
-    // else from the image's lists again
-    int base = 0;
-    for (int c = g + 1; c <= p.nseg; c += p.ngroups) {
-      if (gs.cls_cnt[c] == 0) continue;   // (workgroup-uniform; cls_cnt is not touched below)
-      if (m <= YP_GROUP_KEYS) {
-        const LdsClassSrc lsrc{gs.a, m, c};
-        base += class_nms_blockwide<THREADS>(p, b, c, lsrc, gs, pool, base);
-      } else {
-        const PartSrc csrc{p.cand + (size_t)b * p.parts * p.cap_item, p.seg_count + (size_t)b * p.parts, p.parts, p.cap_item, c, 0, 0};
-        base += class_nms_blockwide<THREADS>(p, b, c, csrc, gs, pool, base);
-      }
-    }
-    const int want = min(p.max_dets, YP_SORT_MAX);
-    if (base > want) {
-      // cut the pooled list to the group's best max_dets (see step 6): read back from L2, where the
-      // write-through stores of all waves are once they have drained
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      const ListSrc ls{pool, base};
-      base = select_topk_sorted<THREADS>(ls, base, want, gs.sh, gs.stage, YP_GSTAGE_CAP);
-      if (t < base) store_wt(&pool[t], gs.sh.key[t]);
-    }
-    if (t == 0) store_wt(&p.pool_count[(size_t)b * p.ngroups + g], base);
-    STAMP(7);
+  if (m > YP_GROUP_CAP || novf > 0) {
+    group_nms_slow<THREADS>(p, b, g, m, novf, gs, pool, pbox);
     return;
   }
-  // 2. class offsets (exclusive prefix over the 256 possible class ids)
-  int cv = 0, incl = 0;
+  //    (longer lists: the remaining candidates, now that the length is known)
+#pragma unroll
+  for (int u = 1; u < KPT; ++u) {
+    key[u] = 0ull;
+    box[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (u * THREADS < m) {                                        // (workgroup-uniform)
+      const int i = min(t + u * THREADS, m - 1);
+      key[u] = lk[i];
+      box[u] = lb[i];
+    }
+  }
+  // 2. class histogram, class offsets (exclusive prefix over the 256 possible class ids) of the candidates and of
+  //    the candidates inside top_k
+  int cls[KPT];
+#pragma unroll
+  for (int u = 0; u < KPT; ++u) {
+    cls[u] = -1;
+    if (t + u * THREADS < m) {
+      cls[u] = yp_seg_key_class(key[u]);
+      atomicAdd(&gs.cls_cnt[cls[u]], 1);
+    }
+  }
+  __syncthreads();
+  int cv = 0, sv = 0, incl = 0, sincl = 0;
   if (t < 256) {
     cv = gs.cls_cnt[t];
+    sv = min(cv, p.top_k);
     incl = wave_incl_scan(cv);
-    if (lane == 63) gs.sh.wtot[wave] = incl;
+    sincl = wave_incl_scan(sv);
+    if (lane == 63) { gs.sh.wtot[wave] = incl; gs.sh.wtot[4 + wave] = sincl; }
   }
   __syncthreads();
   if (t < 256) {
-    int base = 0;
-    for (int w = 0; w < wave; ++w) base += gs.sh.wtot[w];
+    int base = 0, sbase = 0;
+    for (int w = 0; w < wave; ++w) { base += gs.sh.wtot[w]; sbase += gs.sh.wtot[4 + w]; }
     gs.cls_off[t] = base + incl - cv;
+    gs.cls_soff[t] = sbase + sincl - sv;
+    if (t == 255) gs.nsorted = sbase + sincl;
   }
   __syncthreads();
   STAMP(2);
-  // 3. bucket by class (the order inside a bucket is arbitrary; the ranks below do not depend on it)
-  for (int i = t; i < m; i += THREADS) {
-    const u64 key = gs.a[i];
-    const int c = yp_seg_key_class(key);
-    const int pos = gs.cls_off[c] + atomicAdd(&gs.cls_fill[c], 1);
-    gs.bk[pos] = key;
-    gs.pcls[pos] = (unsigned char)c;
-    gs.psup[pos] = 0;
+  if (gs.nsorted > YP_GROUP_SORTED) {                             // (workgroup-uniform; more classes x top_k than the LDS boxes hold)
+    group_nms_slow<THREADS>(p, b, g, m, novf, gs, pool, pbox);
+    return;
+  }
+  // 3. bucket the keys by class (the order inside a bucket is arbitrary; the ranks below do not depend on it)
+  int bpos[KPT];
+#pragma unroll
+  for (int u = 0; u < KPT; ++u) {
+    bpos[u] = 0;
+    if (cls[u] >= 0) {
+      bpos[u] = gs.cls_off[cls[u]] + atomicAdd(&gs.cls_fill[cls[u]], 1);
+      gs.bk[bpos[u]] = key[u];
+    }
   }
   __syncthreads();
   STAMP(3);
-  // 4. per candidate: fetch prior + offsets (one round trip for the whole group), rank inside the
-  //    class (= number of larger keys: tf.math.top_k order, detection.py:217), decode, and move key
-  //    and box to the sorted position if the rank is inside top_k (detection.py:219)
-  {
-    u64 key[YP_GROUP_KPT];
-    float4 pr[YP_GROUP_KPT], of[YP_GROUP_KPT];
+  // 4. the rank of every candidate inside its class (= number of larger keys: tf.math.top_k order,
+  //    detection.py:217), computed per BUCKET position - neighbouring threads then work on the same class, so the
+  //    loop bounds agree across a wave and the reads of bk[] are broadcasts (per list position, with a wave's
+  //    lanes in different classes, this step took 24 us of a saturated group's time) - and handed to the
+  //    candidate's owner through LDS (the histogram's words, idle here).
+  for (int i = t; i < m; i += THREADS) {
+    const u64 mine = gs.bk[i];
+    const int c = yp_seg_key_class(mine);
+    const int lo = gs.cls_off[c], cnt = gs.cls_cnt[c];
+    int r = 0, q = 0;
+    for (; q + 8 <= cnt; q += 8) {                                // eight independent reads per round trip to LDS
+      u64 kk[8];
 #pragma unroll
-    for (int u = 0; u < YP_GROUP_KPT; ++u) {
-      const int i = t + u * THREADS;
-      key[u] = gs.bk[min(i, m - 1)];
-      const int a = min(yp_seg_key_anchor(key[u]), p.A - 1);
-      pr[u] = p.priors[a];
-      of[u] = p.off[(size_t)b * p.A + a];
+      for (int u = 0; u < 8; ++u) kk[u] = gs.bk[lo + q + u];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) r += kk[u] > mine ? 1 : 0;
     }
+    for (; q < cnt; ++q) r += gs.bk[lo + q] > mine ? 1 : 0;
+    gs.hist[i] = r;
+  }
+  __syncthreads();                                                // bk has been read: box[] takes its place
+  //    sidx = the candidate's place among its class's sorted top_k, or -1 (detection.py:219)
+  int sidx[KPT];
 #pragma unroll
-    for (int u = 0; u < YP_GROUP_KPT; ++u) {
-      const int i = t + u * THREADS;
-      if (i < m) {
-        const int c = yp_seg_key_class(key[u]);
-        const int lo = gs.cls_off[c], cnt = gs.cls_cnt[c];
-        int r = 0;
-        for (int q = 0; q < cnt; ++q) r += gs.bk[lo + q] > key[u] ? 1 : 0;
-        if (r < p.top_k) {
-          gs.a[lo + r] = key[u];
-          gs.box[lo + r] = yp_decode(pr[u], of[u]);                                     // detection.py:79
-        }
-      }
+  for (int u = 0; u < KPT; ++u) {
+    sidx[u] = -1;
+    if (cls[u] >= 0) {
+      const int r = gs.hist[bpos[u]];
+      if (r < p.top_k) sidx[u] = gs.cls_soff[cls[u]] + r;
     }
   }
+  __syncthreads();                                                // the ranks have been read: cmask[] takes their place
+#pragma unroll
+  for (int u = 0; u < KPT; ++u)
+    if (sidx[u] >= 0) {
+      gs.box[sidx[u]] = box[u];
+      gs.cmask[sidx[u]] = yp_cell_mask(box[u], 8.0f / p.img_w, 8.0f / p.img_h);
+    }
   __syncthreads();
   STAMP(4);
   // 5. Fast NMS inside every class: a candidate survives unless a higher-ranked box of its class
-  //    overlaps it by more than the threshold (detection.py:221-234; every candidate has p > conf)
-  //    Class by class, the pairs (i < j) of a class dealt evenly to all threads (pair_sweep).
+  //    overlaps it by more than the threshold (detection.py:221-234; every candidate has p > conf).
   //    Small classes (the usual case: a handful of candidates each) are swept side by side, every class by its
-  //    own share of the threads - one after the other the sweeps took 5.5 us of the 17 a group takes, side by side 4.4, of which ~2.7 are the
-  //    pair tests themselves (~3000 per group at config 2, ~40 VALU operations each); large ones one at a time by everybody.
+  //    own share of the threads; large ones one after the other by everybody (no barrier in between: the
+  //    classes' boxes and flags are disjoint).
   {
     const int ncls = (p.nseg - (g + 1)) / p.ngroups + 1;          // classes g+1, g+1+ngroups, ... <= nseg
     int kmax = 0;
@@ -925,42 +1091,53 @@ __device__ __forceinline__ void group_nms_body(const NmsArgs& p, int b, int g, G
       const int ci = t / tpc, tid = t - ci * tpc;
       if (ci < ncls) {
         const int c = g + 1 + ci * p.ngroups;
-        const int lo = gs.cls_off[c];
+        const int lo = gs.cls_soff[c];
         pair_sweep(gs.box + lo, gs.psup + lo, min(gs.cls_cnt[c], p.top_k), p.nms_thresh, tid, tpc);
       }
     } else {
       for (int c = g + 1; c <= p.nseg; c += p.ngroups) {
-        const int lo = gs.cls_off[c];
+        const int lo = gs.cls_soff[c];
         const int kc = min(gs.cls_cnt[c], p.top_k);
-        pair_sweep(gs.box + lo, gs.psup + lo, kc, p.nms_thresh, t, THREADS);
+        pair_sweep_cells(gs.box + lo, gs.cmask + lo, gs.psup + lo, reinterpret_cast<uint32_t*>(gs.sh.key) + wave * YP_SWEEP_QUEUE, kc,
+                         p.nms_thresh, wave, THREADS / YP_WAVE, lane);
       }
     }
   }
   __syncthreads();
   STAMP(5);
-  for (int i = t; i < m; i += THREADS) {
-    const int c = gs.pcls[i];
-    if (gs.psup[i] == 0 && i - gs.cls_off[c] < min(gs.cls_cnt[c], p.top_k)) {
-      const u64 key = gs.a[i];
-      gs.bk[lds_append_slot(&gs.npool)] = yp_fin_key(yp_key_score(key), yp_seg_key_anchor(key), c);
+  // 6. the group's survivors, dense, for the cross-class selection (detection.py:234-239): key and box go from
+  //    the owning thread's registers straight to the pool.  Only a group's best max_dets can be among the
+  //    image's best max_dets: a longer list is cut to them here, by all groups at once, so that the image's
+  //    selection always fits its LDS stage and its first batch of loads.
+  int pslot[KPT];
+#pragma unroll
+  for (int u = 0; u < KPT; ++u) {
+    pslot[u] = -1;
+    if (sidx[u] >= 0 && gs.psup[sidx[u]] == 0) {
+      pslot[u] = lds_append_slot(&gs.npool);
+      key[u] = yp_fin_key(yp_key_score(key[u]), yp_seg_key_anchor(key[u]), cls[u]);
     }
   }
   __syncthreads();
-  STAMP(6);
-  // 6. the group's survivors, dense, for the cross-class selection (detection.py:234-239).  Only a
-  //    group's best max_dets can be among the image's best max_dets: a longer list is cut to them here,
-  //    by all groups at once, so that the image's selection always fits its LDS stage.
   int np = gs.npool;
-  const u64* out = gs.bk;
   const int want = min(p.max_dets, YP_SORT_MAX);
-  if (np > want) {
-    const ListSrc ls{gs.bk, np};
-    np = select_topk_sorted<THREADS>(ls, np, want, gs.sh, nullptr, 0);   // (hist lies over box[], no longer needed)
-    out = gs.sh.key;
+  if (np > want) {                                                // (workgroup-uniform)
+#pragma unroll
+    for (int u = 0; u < KPT; ++u)
+      if (pslot[u] >= 0) gs.stage[pslot[u]] = key[u];             // (box[] has been swept: the stage takes its place)
+    __syncthreads();
+    const ListSrc ls{gs.stage, np};
+    np = select_topk_sorted<THREADS>(ls, np, want, gs.sh, nullptr, 0);
+    const u64 kth = gs.sh.key[np - 1];
+#pragma unroll
+    for (int u = 0; u < KPT; ++u)
+      if (pslot[u] >= 0) pslot[u] = key[u] >= kth ? rank_desc(gs.sh.key, np, key[u]) : -1;
   }
-  for (int i = t; i < np; i += THREADS) store_wt(&pool[i], out[i]);
+#pragma unroll
+  for (int u = 0; u < KPT; ++u)
+    if (pslot[u] >= 0) { store_wt(&pool[pslot[u]], key[u]); store_wt(&pbox[pslot[u]], box[u]); }
   if (t == 0) store_wt(&p.pool_count[(size_t)b * p.ngroups + g], np);
-  STAMP(7);
+  STAMP(6);
 }
 
 // Per-class mode: cross-class top max_dets over the pooled survivors (detection.py:242-248), run by
@@ -972,11 +1149,20 @@ __device__ __forceinline__ void final_select_body(const NmsArgs& p, int b, Group
   const int t = threadIdx.x;
   STAMP_INIT(1, b);
   STAMP(0);
-  // one round trip: the groups' list lengths, the first batch of their keys, the survivor counts
-  PoolSrc src{p.pool + (size_t)b * p.ngroups * p.gcap, start, p.ngroups, p.gcap, nullptr};
-  u64 pre[YP_POOL_PRE];
-  src.preload(pre);
-  src.pre = pre;
+  // ONE round trip: the groups' list lengths, the first batch of their keys (and boxes), the survivor counts
+  PoolSrc src{p.pool + (size_t)b * p.ngroups * p.gcap, start, p.ngroups, p.gcap, {}};
+  const int sft = src.shift(), lpp = 1 << sft;
+  const int sl = min(t, (p.ngroups << sft) - 1);
+  const int pg = sl >> sft, pq = sl & (lpp - 1);
+  const u64* const pl = src.base + (size_t)pg * p.gcap;
+  const float4* const plb = p.pool_box + ((size_t)b * p.ngroups + pg) * p.gcap;
+  float4 preb[YP_POOL_PRE_BOX];
+#pragma unroll
+  for (int u = 0; u < YP_POOL_PRE; ++u) {
+    const int i = min(pq + u * lpp, p.gcap - 1);
+    src.pre[u] = pl[i];
+    if (u < YP_POOL_PRE_BOX) preb[u] = plb[i];
+  }
   int cnt = 0;
   if (t < p.ngroups) cnt = p.pool_count[(size_t)b * p.ngroups + t];
   int part = 0;
@@ -997,13 +1183,24 @@ __device__ __forceinline__ void final_select_body(const NmsArgs& p, int b, Group
     k = select_topk_sorted<THREADS>(src, n, min(p.max_dets, YP_SORT_MAX), sh, gs.stage, YP_GSTAGE_CAP);
 #endif
     STAMP(2);
-    if (t < k) {
-      const u64 key = sh.key[t];
-      const int anchor = min(yp_fin_key_anchor(key), p.A - 1);
-      const float4 pr = p.priors[anchor], of = p.off[(size_t)b * p.A + anchor];
-      CoefRow cf;
-      load_coef(p, b, anchor, cf);
-      emit_row(p, b, t, yp_key_score(key), yp_fin_key_class(key), anchor, yp_decode(pr, of), cf);
+    // every thread that holds one of the selected keys writes that detection's row, at the key's rank
+    if (t < (p.ngroups << sft)) {
+      const u64 kth = sh.key[k - 1];
+      const int ng = start[pg + 1] - start[pg];
+#pragma unroll
+      for (int u = 0; u < YP_POOL_PRE; ++u) {
+        const int i = pq + u * lpp;
+        if (i < ng && src.pre[u] >= kth) {
+          const u64 key = src.pre[u];
+          const float4 bx = u < YP_POOL_PRE_BOX ? preb[u < YP_POOL_PRE_BOX ? u : 0] : plb[i];
+          emit_row(p, b, rank_desc(sh.key, k, key), yp_key_score(key), yp_fin_key_class(key), min(yp_fin_key_anchor(key), p.A - 1), bx);
+        }
+      }
+      for (int i = pq + lpp * YP_POOL_PRE; i < ng; i += lpp) {   // (never with 16 groups: a group pools <= 256 keys)
+        const u64 key = pl[i];
+        if (key >= kth)
+          emit_row(p, b, rank_desc(sh.key, k, key), yp_key_score(key), yp_fin_key_class(key), min(yp_fin_key_anchor(key), p.A - 1), plb[i]);
+      }
     }
   }
   STAMP(3);
@@ -1040,6 +1237,7 @@ __global__ __launch_bounds__(THREADS, YP_GROUP_MIN_WAVES) void group_nms_kernel(
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       p.arrive[b] = 0;                               // ready for the next launch (kernel boundary in between)
+      p.ocount[(size_t)b * YP_CNT_STRIDE] = 0;       // every group of the image has read it
     }
     gs.last = last;
   }
@@ -1048,13 +1246,14 @@ __global__ __launch_bounds__(THREADS, YP_GROUP_MIN_WAVES) void group_nms_kernel(
   final_select_body<THREADS>(p, b, gs);
 }
 
-static NmsArgs make_args(const yp_handle* h, int batch, const float* pred_offset, const float* priors, const float* pred_mask_coef,
+static NmsArgs make_args(const yp_handle* h, int batch, const float* pred_offset, const float* priors,
                          float* det_boxes, float* det_classes, float* det_scores, int32_t* num_det, int32_t* kept_idx) {
   NmsArgs a;
-  a.cand = h->s.cand; a.seg_count = h->s.seg_count; a.seg_surv = h->s.seg_surv; a.stat_surv = h->s.stat_surv;
+  a.lkeys = h->s.lkeys; a.lbox = h->s.lbox; a.lcount = h->s.lcount; a.okeys = h->s.okeys; a.ocount = h->s.ocount;
+  a.seg_surv = h->s.seg_surv; a.stat_surv = h->s.stat_surv;
   a.off = reinterpret_cast<const float4*>(pred_offset); a.priors = reinterpret_cast<const float4*>(priors);
-  a.pool = h->s.pool; a.pool_count = h->s.pool_count; a.crop = h->s.crop;
-  a.coef_out = h->s.coef; a.coef_in = pred_mask_coef;
+  a.pool = h->s.pool; a.pool_box = h->s.pool_box; a.pool_count = h->s.pool_count; a.crop = h->s.crop;
+  a.sel_anchor = h->s.sel_anchor;
   a.det_boxes = det_boxes; a.det_classes = det_classes; a.det_scores = det_scores; a.num_det = num_det;
   a.kept_idx = kept_idx;
   a.A = h->cfg.num_anchors; a.nseg = h->nseg; a.top_k = h->cfg.top_k; a.max_dets = h->cfg.max_dets;
@@ -1063,8 +1262,12 @@ static NmsArgs make_args(const yp_handle* h, int batch, const float* pred_offset
   a.img_h = (float)h->cfg.img_h; a.img_w = (float)h->cfg.img_w;
   a.proto_h = (float)h->cfg.proto_h; a.proto_w = (float)h->cfg.proto_w;
   a.use_crop = h->cfg.use_cropped_mask;
-  yp_plan_items(h, batch, &a.parts, &a.cap_item);
+  {
+    int longest;
+    yp_plan_items(h, batch, &a.parts, &longest);
+  }
   yp_plan_groups(h, &a.ngroups, &a.gcap);
+  yp_plan_lists(h, batch, &a.lcap, &a.ocap);
 #ifdef YP_STAMPS
   a.dbg = (unsigned long long*)h->dbg;
 #endif
@@ -1073,16 +1276,15 @@ static NmsArgs make_args(const yp_handle* h, int batch, const float* pred_offset
 
 // NMS (both modes; in per-class mode including the final selection) plus, when fill_masks is given,
 // the zero-fill of rows [0, fill_rows) of every image's masks (and bitmaps) as extra workgroups.
-hipError_t yp_launch_nms(const yp_handle* h, int batch, const float* pred_offset, const float* priors,
-                         const float* pred_mask_coef, float* det_boxes,
+hipError_t yp_launch_nms(const yp_handle* h, int batch, const float* pred_offset, const float* priors, float* det_boxes,
                          float* det_classes, float* det_scores, int32_t* num_det, int32_t* kept_idx,
                          float* fill_masks, uint8_t* fill_bitmaps, int fill_rows, hipStream_t st) {
-  NmsArgs a = make_args(h, batch, pred_offset, priors, pred_mask_coef, det_boxes, det_classes, det_scores, num_det, kept_idx);
+  NmsArgs a = make_args(h, batch, pred_offset, priors, det_boxes, det_classes, det_scores, num_det, kept_idx);
   a.arrive = h->s.arrive;
   a.fill_masks = fill_masks; a.fill_bitmaps = fill_masks ? fill_bitmaps : nullptr;
   a.fill_P = (long long)h->cfg.proto_h * h->cfg.proto_w; a.fill_rows = fill_rows; a.batch = batch;
   if (h->cfg.nms_mode == YP_NMS_CROSS_CLASS) {
-    constexpr int T = 1024;
+    constexpr int T = YP_CC_THREADS;
     a.nms_blocks = batch;
     long long nfill = 0;
     if (a.fill_masks) nfill += fill_chunks_per_image<T>(a.fill_P, fill_rows, 4) * batch;

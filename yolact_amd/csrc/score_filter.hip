@@ -8,23 +8,33 @@
 // HBM-bound: the [B,A,C] logits are read exactly once (4*A*C bytes per image) with non-temporal
 // 16-byte loads.  The batch is cut into `nitems` work items, `parts` per image, each a run of
 // consecutive 32-anchor tiles of ONE image; one single-wave workgroup owns an item from start to
-// end, so everything it emits goes to a list of its own - a dense run of 64-bit keys plus one count
-// - with plain coalesced stores and no atomics.  The item count is chosen so that all items are
-// resident at once (one round, no tail).
+// end.  The item count is chosen so that all items are resident at once (one round, no tail).
+// What an item emits is parked in LDS and leaves - normally once, at the item's end - for the lists the
+// NMS launch reads: YP_NLISTS lists per image (per-class mode: one per class group, so that a group's
+// workgroup finds exactly its candidates; cross-class mode: the image's items dealt round-robin), every
+// entry a 64-bit key plus the candidate's DECODED BOX (prior and offsets gathered here, utils._decode
+// evaluated once), so that the NMS workgroups get everything they need in one round trip and never
+// gather from the cold pred_offset array.  The slots come from one agent-scope atomic per (flush, list),
+// issued back to back; every list counter sits on a cache line of its own.
 #include <stdlib.h>
 #include "common.hpp"
 
 struct ScoreFilterArgs {
   const float* cls;      // [B,A,C]
-  u64* cand;             // [nitems][cap_item] keys (yp_seg_key), dense from the front of every list
-  int32_t* seg_count;    // [nitems] keys in the list
+  const float4* off;     // [B,A] pred_offset (dx,dy,dw,dh)
+  const float4* priors;  // [A]   (ymin,xmin,ymax,xmax) pixels
+  u64* lkeys;            // [B][YP_NLISTS][lcap] keys (yp_seg_key), see common.hpp yp_scratch
+  float4* lbox;          // [B][YP_NLISTS][lcap] decoded boxes
+  int32_t* lcount;       // [B][YP_NLISTS] x YP_CNT_STRIDE
+  u64* okeys;            // [B][ocap] keys that found their list full (per-class mode)
+  int32_t* ocount;       // [B] x YP_CNT_STRIDE
   int32_t* seg_surv;     // [nitems] anchors past the confidence filter
-  int A, C, stride, ntiles, parts, nitems;
-  long long cap_item;
+  int A, C, stride, ntiles, parts, nitems, ngroups;
+  long long lcap, ocap;
   int bufb;              // bytes of the LDS tile buffer
   int fast;              // 1: stride == C and every tile starts 16-byte aligned -> wide-load path
   float conf, conf_lo;
-  int32_t* overflow;     // [1] set when an item emitted more keys than cap_item
+  int32_t* overflow;     // [1] set when a key found both its list and the image's overflow list full
   float pre_thresh;      // ln(1/conf - 1) + 1e-3: x_bg - x_fgmax must be below it to have p_fgmax > conf
   float jen_thr, jen_n, jen_inv_n;   // second reject: (1/conf)(1+1e-3) + 0.1 (NaN = off), C-2, 1/(C-2)
 };
@@ -95,7 +105,8 @@ __device__ __forceinline__ int grp8_min(int v) {
 #ifndef YP_SF_MIN_WAVES
 #define YP_SF_MIN_WAVES 1   // waves per SIMD the register allocation must allow
 #endif
-#define YP_SF_KCAP 128   // keys the LDS hand-off buffer holds
+#define YP_SF_KCAP 224   // keys the LDS hand-off buffer holds (with the tile of C = 81 the wave still takes ten
+                         // 1280-byte LDS units: 12 waves per CU); an ordinary item (~40 keys) flushes once, at its end
 
 // One wave walks the tiles of its item.  Per tile of TA = 32 consecutive anchors (TA*C contiguous
 // floats in HBM):
@@ -113,7 +124,8 @@ __device__ __forceinline__ int grp8_min(int v) {
 //            sequential sums plus one tree ((j,j+8) in the lane, then j^4, j^2, j^1 by DPP).  Eight
 //            anchors per round amortise the trees, the division and the bookkeeping over twice as
 //            many anchors as sixteen lanes per anchor did: the kernel is bound by instruction issue.
-//   phase 3  keys collect in LDS and leave in runs of >= 64 for the item's list
+//   phase 3  keys collect in LDS and leave - key + decoded box - for the image's lists when the buffer
+//            fills up and at the item's end
 // FAST (compile time, so that no path exists on which staged loads are pending and nobody stores them):
 // rows are dense in LDS (stride == C) and the logits 16-byte aligned - the register-staged pipeline;
 // otherwise a plain element-wise tile copy.
@@ -138,6 +150,7 @@ __global__ __launch_bounds__(YP_WAVE, YP_SF_MIN_WAVES) void score_filter_kernel(
     okf[i] = (j + 8 * i) < C ? 1.0f : 0.0f;
   }
   const u64 lt_mask = (1ull << lane) - 1ull;
+  const float ginv = 1.0f / (float)max(p.ngroups, 1);
   const int lane16 = lane * 16;
   const long long img_bytes = (long long)p.A * C * 4;
   const long long tile_bytes = (long long)TA * C * 4;
@@ -148,6 +161,10 @@ __global__ __launch_bounds__(YP_WAVE, YP_SF_MIN_WAVES) void score_filter_kernel(
   // nobody reads - and with `on` false (no next tile) the descriptor has no records, so the same
   // instructions fetch nothing.  The loads are thereby unconditional: one register set, no copies, and
   // the compiler's wait for them sits at the LDS stores of the next iteration and nowhere else.
+  // The whole per-load offset (lane16 + u KiB) travels as the VGPR offset (the compiler folds what fits
+  // into the instruction's 12-bit immediate): the hardware range-checks VGPR offset + immediate only, an
+  // SGPR offset is outside the check, and with it loads u >= 1 of a short last tile would read past the
+  // end of pred_cls (tests/test_gpu_parity.py::test_score_filter_reads_nothing_past_pred_cls).
   typedef unsigned int raw4 __attribute__((__vector_size__(4 * sizeof(unsigned int))));
   auto issue_loads = [&](int bb, int tt, bool on) {
     const int nbytes = on ? min(TA, p.A - tt * TA) * C * 4 : 0;
@@ -155,22 +172,66 @@ __global__ __launch_bounds__(YP_WAVE, YP_SF_MIN_WAVES) void score_filter_kernel(
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(g), 0, nbytes, 0x00020000);
 #pragma unroll
     for (int u = 0; u < NLD; ++u)
-      stg[u] = __builtin_bit_cast(nat4, (raw4)__builtin_amdgcn_raw_buffer_load_b128(rsrc, lane16, u * 1024, YP_SF_AUX));
+      stg[u] = __builtin_bit_cast(nat4, (raw4)__builtin_amdgcn_raw_buffer_load_b128(rsrc, lane16 + u * 1024, 0, YP_SF_AUX));
   };
 
   for (int item = blockIdx.x; item < p.nitems; item += gridDim.x) {
     const int b = item / p.parts, part = item - b * p.parts;
     const int t_begin = (int)(((long long)part * p.ntiles) / p.parts);
     const int t_end = (int)(((long long)(part + 1) * p.ntiles) / p.parts);
-    u64* const out = p.cand + (size_t)item * p.cap_item;
-    int nout = 0;    // keys already in the item's list
     int nbuf = 0;    // keys parked in s_key
     int nsurv = 0;   // anchors past the confidence filter
+    // The parked keys leave for the image's lists, 64 at a time: every lane takes one key, fetches its anchor's
+    // prior and offsets, and - while those loads are in flight - the wave reserves slots with ONE atomic
+    // instruction: the lowest lane of every list that occurs among the 64 keys adds that list's share, all of them
+    // in the same instruction.  (One instruction per list, issued back to back, cost 8 us per launch at config 2
+    // and 30 at config 4: a wave's returning agent-scope atomics are served one after the other, ~0.5 us each;
+    // tools/atomic_probe.hip.)
     auto flush = [&]() {   // wave-uniform
       __builtin_amdgcn_wave_barrier();
-      for (int l = lane; l < nbuf; l += YP_WAVE)
-        if (nout + l < p.cap_item) out[nout + l] = s_key[l];
-      nout += nbuf;
+      for (int l0 = 0; l0 < nbuf; l0 += YP_WAVE) {
+        const bool has = l0 + lane < nbuf;
+        const u64 key = s_key[min(l0 + lane, nbuf - 1)];
+        const int anchor = min(yp_seg_key_anchor(key), p.A - 1);
+        const float4 pr = p.priors[anchor], of = p.off[(size_t)b * p.A + anchor];
+        int lst;
+        if (MODE == YP_NMS_CROSS_CLASS) {
+          lst = part & (YP_NLISTS - 1);
+        } else {
+          // (c - 1) % ngroups without the integer division: (x + 0.5) / n is at least 0.5 / n away from an
+          // integer for 0 <= x < 256, n <= 16 - far more than the float error - so the truncation is x / n
+          const int c1 = yp_seg_key_class(key) - 1;
+          lst = c1 - (int)(((float)c1 + 0.5f) * ginv) * p.ngroups;
+        }
+        int32_t* const cnt = p.lcount + ((size_t)b * YP_NLISTS) * YP_CNT_STRIDE;
+        u64 rest = __ballot(has);
+        int base = 0, leader = 0, rank = 0, share = 0;
+        while (rest != 0ull) {   // (one trip in cross-class mode; no memory operation inside)
+          const int l1 = __builtin_ctzll(rest);
+          const int g1 = __builtin_amdgcn_readlane(lst, l1);
+          const u64 mm = __ballot(lst == g1) & rest;
+          if (has && lst == g1) { leader = l1; rank = __popcll(mm & lt_mask); }
+          if (lane == l1) share = __popcll(mm);
+          rest &= ~mm;
+        }
+        if (share != 0) base = __hip_atomic_fetch_add(cnt + lst * YP_CNT_STRIDE, share, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const float4 box = yp_decode(pr, of);                                             // detection.py:79
+        const int slot = __shfl(base, leader) + rank;
+        if (has) {
+          if (slot < p.lcap) {
+            const size_t o = ((size_t)b * YP_NLISTS + lst) * p.lcap + slot;
+            p.lkeys[o] = key;
+            p.lbox[o] = box;
+          } else {
+            // the list is full (only a batch far from anything a detector emits gets here): the key alone goes
+            // to the image's overflow list, which every class group then also reads
+            const int os = p.ocap > 0 ? __hip_atomic_fetch_add(p.ocount + (size_t)b * YP_CNT_STRIDE, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                      : 0x7fffffff;
+            if (os < p.ocap) p.okeys[(size_t)b * p.ocap + os] = key;
+            else *p.overflow = 1;   // (bounded lists only: the key is dropped)
+          }
+        }
+      }
       nbuf = 0;
     };
     if (FAST) issue_loads(b, t_begin, t_begin < t_end);
@@ -285,8 +346,11 @@ __global__ __launch_bounds__(YP_WAVE, YP_SF_MIN_WAVES) void score_filter_kernel(
         for (int i = 1; i < CPL; ++i) em = max_nonneg(em, e[i]);   // e >= 0: integer max on the bit patterns
         const float S = grp8_sum(s_lo, s_hi);
         em = grp8_max_nonneg(em);
-        // IEEE division is monotone, so max_c fl(e_c/S) = fl(max_c e_c / S)              (detection.py:62)
-        const float pmax = em / S;
+        // YP-MATH softmax: p_c = fl(e_c * rS) with rS = fl(1/S) - one IEEE reciprocal per anchor, then a
+        // multiply per class (Eigen's form of tf.nn.softmax).  Multiplication by a positive
+        // constant is monotone under rounding, so max_c fl(e_c*rS) = fl(max_c e_c * rS)  (detection.py:62)
+        const float rS = 1.0f / S;
+        const float pmax = em * rS;
         const bool surv = act && (pmax > p.conf);                                      // detection.py:73
         const bool lead = surv && j == 0;
         const u64 bl = __ballot(lead);
@@ -294,9 +358,12 @@ __global__ __launch_bounds__(YP_WAVE, YP_SF_MIN_WAVES) void score_filter_kernel(
         if (bl == 0) continue;   // (wave-uniform) nobody in this round passed: nothing to emit
         if (MODE == YP_NMS_CROSS_CLASS) {
           // tf.argmax over the probabilities (detection.py:184): the FIRST class whose rounded
-          // probability equals the maximum.  Only an e_c within 2^-21 of the largest can round to it;
-          // almost always that is one class, found without any division.
-          const float ethr = em * (1.0f - 0x1p-21f);
+          // probability equals the maximum.  fl(e_c*rS) = fl(em*rS) needs e_c >= em (1 - 2^-23) while the
+          // products are normal numbers, so only an e_c within 2^-21 of the largest can tie; almost always
+          // that is one class, found without any multiply.  (A subnormal pmax - conf = 0 and a foreground
+          // maximum ~87 below the row maximum - has no relative precision: every real class is then a
+          // candidate for the exact test; e_c of a real class is >= exp(-87) > 0, the padding slots hold 0.)
+          const float ethr = pmax >= 0x1p-100f ? em * (1.0f - 0x1p-21f) : 0x1p-149f;
           int cnt = 0, cmin = 0x7fffffff;
 #pragma unroll
           for (int i = 0; i < CPL; ++i) {
@@ -311,15 +378,17 @@ __global__ __launch_bounds__(YP_WAVE, YP_SF_MIN_WAVES) void score_filter_kernel(
 #pragma unroll
             for (int i = 0; i < CPL; ++i) {
               const bool hit = (e[i] >= ethr) && (i > 0 || j > 0);
-              if (hit && (e[i] / S == pmax)) a2 = min(a2, j + 8 * i);
+              if (hit && (e[i] * rS == pmax)) a2 = min(a2, j + 8 * i);
             }
             a2 = grp8_min(a2);
             if (cnt > 1) arg = a2;
           }
           if (lead) s_key[nbuf + __popcll(bl & lt_mask)] = yp_seg_key(pmax, a0 + al, arg);
-          nbuf += __popcll(bl);   // <= 8 per round, <= 32 per tile: flushed between tiles
+          nbuf += __popcll(bl);   // <= 8 per round, <= 32 per tile: flushed between tiles when a tile's worth of room is gone
         } else {
           // per-class candidates: every (anchor, class) with p > conf                 (detection.py:233)
+          // fl(e_c*rS) > conf implies e_c > conf S (1 - 2^-23) (two roundings of 2^-24 each), and
+          // elo = fl(S fl(conf (1 - 2^-20))) lies below that: no candidate is lost by testing e_c >= elo first
           const float elo = S * p.conf_lo;
           int nhit = 0, csel = 0;
           float esel = 0.0f;
@@ -332,7 +401,7 @@ __global__ __launch_bounds__(YP_WAVE, YP_SF_MIN_WAVES) void score_filter_kernel(
           }
           if (__ballot(nhit > 1) == 0) {
             // common: at most one class per lane, <= 64 keys (the buffer holds <= KCAP - 64 here)
-            const float pc = esel / S;
+            const float pc = esel * rS;
             const bool has = (nhit == 1) && (pc > p.conf);
             const u64 bm = __ballot(has);
             if (has) s_key[nbuf + __popcll(bm & lt_mask)] = yp_seg_key(pc, a0 + al, csel);
@@ -343,7 +412,7 @@ __global__ __launch_bounds__(YP_WAVE, YP_SF_MIN_WAVES) void score_filter_kernel(
               bool has = false;
               float pc = 0.0f;
               if (surv && (e[i] >= elo) && (i > 0 || j > 0)) {
-                pc = e[i] / S;
+                pc = e[i] * rS;
                 has = pc > p.conf;
               }
               const u64 bm = __ballot(has);
@@ -358,17 +427,13 @@ __global__ __launch_bounds__(YP_WAVE, YP_SF_MIN_WAVES) void score_filter_kernel(
         }
       }
       // ---- phase 3 --------------------------------------------------------------------------------
-      if (MODE == YP_NMS_CROSS_CLASS && nbuf >= YP_WAVE) flush();
+      if (MODE == YP_NMS_CROSS_CLASS && nbuf > YP_SF_KCAP - TA) flush();
       // every LDS read of this tile has returned before the next iteration overwrites the buffer
       __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0)
       __builtin_amdgcn_wave_barrier();
     }   // tile loop
     if (nbuf > 0) flush();
-    if (lane == 0) {
-      p.seg_count[item] = nout < p.cap_item ? nout : (int)p.cap_item;
-      if (nout > p.cap_item) *p.overflow = 1;     // (bounded lists only: the item's last keys were dropped)
-      p.seg_surv[item] = nsurv;
-    }
+    if (lane == 0) p.seg_surv[item] = nsurv;
     __builtin_amdgcn_s_waitcnt(0xC07F);
     __builtin_amdgcn_wave_barrier();
   }   // item loop
@@ -420,17 +485,28 @@ int yp_score_filter_waves_per_cu(const yp_handle* h) {
   return per_cu < 1 ? 1 : (per_cu > 32 ? 32 : per_cu);
 }
 
-hipError_t yp_launch_score_filter(const yp_handle* h, int batch, const float* pred_cls, hipStream_t st) {
+hipError_t yp_launch_score_filter(const yp_handle* h, int batch, const float* pred_cls, const float* pred_offset,
+                                  const float* priors, hipStream_t st) {
   ScoreFilterArgs a;
   a.cls = pred_cls;
-  a.cand = h->s.cand; a.seg_count = h->s.seg_count; a.seg_surv = h->s.seg_surv; a.overflow = h->s.overflow;
+  a.off = reinterpret_cast<const float4*>(pred_offset); a.priors = reinterpret_cast<const float4*>(priors);
+  a.lkeys = h->s.lkeys; a.lbox = h->s.lbox; a.lcount = h->s.lcount; a.okeys = h->s.okeys; a.ocount = h->s.ocount;
+  a.seg_surv = h->s.seg_surv; a.overflow = h->s.overflow;
+  {
+    int gcap;
+    yp_plan_groups(h, &a.ngroups, &gcap);
+    yp_plan_lists(h, batch, &a.lcap, &a.ocap);
+  }
   a.A = h->cfg.num_anchors; a.C = h->cfg.num_classes; a.stride = h->lds_stride;
   a.conf = h->cfg.conf_thresh;
   a.conf_lo = h->cfg.conf_thresh * (1.0f - 0x1p-20f);
   a.pre_thresh = h->pre_thresh;
   a.jen_thr = h->jen_thr; a.jen_n = (float)(a.C - 2); a.jen_inv_n = a.C > 2 ? 1.0f / (float)(a.C - 2) : 0.0f;
   a.ntiles = (a.A + YP_SF_TA - 1) / YP_SF_TA;
-  yp_plan_items(h, batch, &a.parts, &a.cap_item);
+  {
+    int longest;
+    yp_plan_items(h, batch, &a.parts, &longest);
+  }
   a.nitems = batch * a.parts;
   a.bufb = tile_lds_bytes(h);
   a.fast = (a.stride == a.C) && (((long long)a.A * a.C) % 4 == 0) && ((((uintptr_t)pred_cls) & 15u) == 0);
