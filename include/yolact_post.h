@@ -21,8 +21,8 @@
  * Experiment knobs (environment, read ONCE in yp_create, never on the launch
  * path): YP_TUNE_MASK_NT=1 (non-temporal mask stores), YP_TUNE_SF_WAVES=<n>
  * (score_filter workgroups per CU the plan assumes), YP_TUNE_PREFILL=0|1
- * (mask rows zero-filled by mask_assemble itself / by fill workgroups inside the
- * NMS launch (default)).
+ * (mask rows zero-filled by a launch of its own before mask_assemble / by fill
+ * workgroups inside the NMS launch (default)).
  */
 #ifndef YOLACT_POST_H
 #define YOLACT_POST_H
@@ -68,10 +68,9 @@ typedef struct yp_config {
   int32_t use_cropped_mask; /* detection.py:102 (1 in every reference call)            */
   int32_t zero_pad_masks;   /* 1: every mask row >= num_det is written as zeros, which
                                is the reference's tf.zeros layout (detection.py:68);
-                               0: rows >= num_det are either untouched or zeros
-                               (zeros where the library pre-fills the rows a
-                               detection can land in: rows < min(max_dets, 256),
-                               and < top_k in cross-class mode)                        */
+                               0: rows >= num_det are zeros where a detection could
+                               have landed (rows < min(max_dets, 256), and < top_k
+                               in cross-class mode) and untouched beyond            */
   float mask_threshold;     /* < 0: float masks only.  >= 0: det_bitmaps = mask > thr
                                (the callers' binarisation, train.py:497)               */
   int32_t max_batch;        /* largest batch yp_run will be given                      */

@@ -495,9 +495,9 @@ def test_batches_that_pad_the_xcd_placement(torch_cuda, nb):
 @pytest.mark.parametrize("prefill", [0, 1])
 def test_untouched_and_zero_rows_contract(torch_cuda, prefill, monkeypatch):
     """include/yolact_post.h, zero_pad_masks = 0: rows beyond the rows a detection can land in keep what
-    the caller had there; rows in [num_det, that bound) are zeros when the separate zero-fill ran
-    (YP_TUNE_PREFILL=1, the default for large outputs) and untouched otherwise.  Both zero-fill paths
-    are bit-exact on the detections' rows."""
+    the caller had there; rows in [num_det, that bound) are zeros, whether the zero-fill rode in the NMS
+    launch (YP_TUNE_PREFILL=1, the default) or ran as a launch of its own (0).  Both placements are
+    bit-exact on the detections' rows."""
     import torch
     from oracle import c_oracle as co
     from yolact_amd import PostConfig, PostProcessor, synth
@@ -518,7 +518,7 @@ def test_untouched_and_zero_rows_contract(torch_cuda, prefill, monkeypatch):
         for b in range(B):
             assert n[b] <= bound and (m[b, bound:] == 7.0).all()
             tail = m[b, n[b]:bound]
-            assert (not tail.any()) if prefill else (tail == 7.0).all()
+            assert not tail.any()
         pp.close()
 
 

@@ -258,6 +258,7 @@ hipError_t yp_launch_nms(const yp_handle* h, int batch, const float* pred_offset
                          float* det_classes, float* det_scores, int32_t* num_det, int32_t* kept_idx,
                          float* fill_masks, uint8_t* fill_bitmaps, int fill_rows, hipStream_t st);
 int yp_mask_fill_rows(const yp_handle* h);
+hipError_t yp_launch_fill(float* masks, uint8_t* bitmaps, long long P, int fill_rows, int max_dets, int batch, hipStream_t st);
 int yp_mask_prefill(const yp_handle* h, int batch);
 hipError_t yp_launch_mask_assemble(const yp_handle* h, int batch, const float* proto, const float* pred_mask_coef,
                                    const int32_t* num_det, float* det_masks, uint8_t* det_bitmaps, hipStream_t st);

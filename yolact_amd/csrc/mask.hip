@@ -4,15 +4,16 @@
 // (utils/utils.py:119-133), detection.py:105-107 (clip, transpose to [N,ph,pw]) and the mask
 // scatter of detection.py:113.
 //
-// HBM-bound by the N*4*P bytes of masks it writes per image (K=32 gives ~12 flop/byte, below the
-// ~25 flop/byte balance of 157 TFLOP/s fp32 over ~6.3 TB/s).  A lane owns one proto pixel and
-// keeps its 32 prototype values in VGPRs for the whole kernel, so the prototypes are read from
-// HBM exactly once; the coefficients and crop edges of a detection are wave-uniform and come in
-// through scalar loads.  The dot product is a K-ordered fma chain (YP-MATH) and is only evaluated
-// by waves whose 64 pixels can lie inside the detection's crop box; everything else is zeros, written
-// in bulk: by the fill workgroups that ride in the NMS launch (nms.hip fill_block; the default), or by
-// pass Z below.
-// Output is written [N][P] (pixel-contiguous), which is the reference's final layout.
+// HBM-bound by the prototypes it reads (4*P*32 bytes per image, once) - the mask rows are zeros already,
+// written in bulk by the fill workgroups that ride in the NMS launch (nms.hip fill_block) or by a fill
+// launch of their own - and, beside that, by the vector ALU: every detection a wave visits costs a 32-term
+// fma chain and a sigmoid on all 64 lanes, whatever share of them lies inside the box.  So a wave owns an
+// 8 x 8 TILE of proto pixels, not 64 consecutive ones: a crop box of 10 x 11 pixels meets ~5 such tiles with
+// ~45 % of their lanes inside, where it meets ~14 runs of 64 pixels with ~12 % inside (config 2: 2.0 instead
+// of 4.5 visited detections per wave).  A lane keeps its pixel's 32 prototype values in VGPRs; the
+// coefficients and crop edges of a detection are wave-uniform and come in through scalar loads, the
+// coefficient row straight from pred_mask_coef by the detection's anchor.  The dot product is a K-ordered
+// fma chain (YP-MATH).  Output is written [N][P] (pixel-contiguous), which is the reference's final layout.
 #include <stdlib.h>
 #include "common.hpp"
 
@@ -24,28 +25,26 @@ struct MaskArgs {
   int A;
   const float4* crop;      // [B,sel_rows]  (x1,x2,y1,y2)
   const int32_t* num_det;  // [B]
-  float* masks;            // [B,max_dets,P]
-  uint8_t* bitmaps;        // [B,max_dets,P] or null
-  int P, pw, max_dets, sel_rows, zero_pad;
-  int prezeroed;           // 1: the NMS launch's fill workgroups have already zero-filled every row this kernel would
+  float* masks;            // [B,max_dets,P]; every row this kernel can touch holds zeros already
+  uint8_t* bitmaps;        // [B,max_dets,P] or null (zeros already)
+  int P, pw, ph, max_dets, sel_rows, tiles_x;
   float mask_threshold;
 };
 
 #define YP_MASK_BLOCK 256
+#define YP_MASK_TILE 16  // a workgroup owns a 16 x 16 tile of proto pixels: four waves, an 8 x 8 quadrant each
 #define YP_MASK_ROW4 3   // float4 per pixel row in LDS: 2 of data + 1 of padding (48-byte stride: conflict-free b128 reads)
 
-// One workgroup = 256 consecutive proto pixels of one image; a lane owns one pixel.
-//   1. the block's 256 x 32 prototype values (32 KiB, contiguous in HBM) are fetched with fully
-//      coalesced NON-TEMPORAL 16-byte loads (read once, by nobody else: they must not displace the
-//      output lines that live in L2 / Infinity Cache) and transposed through LDS, so that every lane
-//      ends up with its pixel's 32 values in VGPRs;
-//   2. the rows are zeros first - either zero-filled beforehand by the NMS launch's fill workgroups
-//      or by this kernel's pass Z (16-byte stores, 1 KiB per wave-instruction);
-//      pass R: the detections whose crop box can touch the wave's pixels (one bit each, found with
-//      ctz) get the K-ordered fma chain + sigmoid + crop and are stored over the zeros.
+// One workgroup = one 16 x 16 tile of one image's prototypes; wave w owns the quadrant (w >> 1, w & 1), lane l
+// its pixel (l >> 3, l & 7).
+//   1. the tile's 256 x 32 prototype values - sixteen runs of 2 KiB in HBM - are fetched with coalesced
+//      NON-TEMPORAL 16-byte loads (read once, by nobody else: they must not displace the output lines
+//      that live in L2 / Infinity Cache) and transposed through LDS, so that every lane ends up with its
+//      pixel's 32 values in VGPRs;
+//   2. the detections whose crop box can touch the wave's quadrant (one bit each, found with ctz) get the
+//      K-ordered fma chain + sigmoid + crop and are stored over the zeros.
 // Workgroups of one image are placed on one XCD (the dispatcher deals consecutive workgroup ids
-// round-robin over the 8 XCDs), so the partial cache lines at workgroup borders (mask rows are
-// only 16-byte aligned: P*4 bytes is not a multiple of 128) merge in a single L2.
+// round-robin over the 8 XCDs), so the partial cache lines of neighbouring tiles merge in a single L2.
 template <bool NT_STORE, int NG>   // NG: 64-detection groups the kernel looks at (sel_rows <= 64 * NG)
 __global__ __launch_bounds__(YP_MASK_BLOCK) void mask_assemble_kernel(const MaskArgs p, int blocks_per_image, int batch, int by_xcd) {
   __shared__ float4 sproto[YP_MASK_BLOCK * YP_MASK_ROW4];
@@ -57,43 +56,48 @@ __global__ __launch_bounds__(YP_MASK_BLOCK) void mask_assemble_kernel(const Mask
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
   const int b = by_xcd ? (slot / blocks_per_image) * 8 + xcd : (int)blockIdx.x / blocks_per_image;
   if (b >= batch) return;
-  const int base_pix = (by_xcd ? slot % blocks_per_image : (int)blockIdx.x % blocks_per_image) * YP_MASK_BLOCK;
-  const int npx = min(YP_MASK_BLOCK, p.P - base_pix);
-  const int pix = base_pix + t;
-  const bool live = t < npx;
+  const int tile = by_xcd ? slot % blocks_per_image : (int)blockIdx.x % blocks_per_image;
+  const int ty = tile / p.tiles_x, tx = tile - ty * p.tiles_x;
+  const int row0 = ty * YP_MASK_TILE, col0 = tx * YP_MASK_TILE;      // the tile's first pixel
+  // The detections of the image: the count arrives by a scalar load that nothing below waits for until
+  // the crop rows are tested (their loads are issued without it: rows >= N hold stale values, masked).
   const int N = __builtin_amdgcn_readfirstlane(min(p.num_det[b], p.sel_rows));   // wave-uniform
-  // The block's 256 x 32 prototype values (32 KiB, contiguous in HBM): fully coalesced NON-TEMPORAL
-  // 16-byte loads (read once, by nobody else), issued first so that they are in flight while the
-  // detection rows are looked at.  Thread t's float4 number i is quad (t & 7) of pixel i*32 + (t >> 3).
-  const nat4* src = reinterpret_cast<const nat4*>(p.proto + ((size_t)b * p.P + base_pix) * YP_MASK_DIM);
+  // The tile's prototypes: thread t's float4 number i is quad (t & 7) of the tile's pixel
+  // (2i + (t >> 7), (t & 127) >> 3) - every load instruction of the workgroup covers two whole tile rows
+  // (2 x 2 KiB).  Pixels past the image's edge are read from the edge pixel instead (and never used).
   nat4 x[YP_MASK_DIM / 4];
+  {
+    const int pcol = min(col0 + ((t & 127) >> 3), p.pw - 1);
+    const nat4* src = reinterpret_cast<const nat4*>(p.proto + (size_t)b * p.P * YP_MASK_DIM) + (t & 7);
 #pragma unroll
-  for (int i = 0; i < YP_MASK_DIM / 4; ++i) {
-    const int idx = i * YP_MASK_BLOCK + t;
-    x[i] = __builtin_nontemporal_load(src + min(idx, npx * (YP_MASK_DIM / 4) - 1));
+    for (int i = 0; i < YP_MASK_DIM / 4; ++i) {
+      const int prow = min(row0 + 2 * i + (t >> 7), p.ph - 1);
+      x[i] = __builtin_nontemporal_load(src + ((size_t)prow * p.pw + pcol) * (YP_MASK_DIM / 4));
+    }
   }
 
-  // Which detections can touch this wave's 64 pixels at all?  Lane l tests detection g*64+l against
-  // a bounding range of the wave's pixels (a superset test: the per-pixel compares below decide the
-  // values); the ballots give a bit per detection.  Rows of all other detections are plain zeros.  Everything wave-uniform is kept in SGPRs on purpose (readfirstlane where
-  // the compiler cannot prove it), so that walking the bits is scalar work.
+  // Which detections can touch this wave's quadrant at all?  Lane l tests detection g*64+l against the
+  // quadrant's rows and columns (a superset test: the per-pixel compares below decide the values); the
+  // ballots give a bit per detection.  Everything wave-uniform is kept in SGPRs on purpose (readfirstlane
+  // where the compiler cannot prove it), so that walking the bits is scalar work.
   const int lane = t & 63;
-  const int w0 = base_pix + __builtin_amdgcn_readfirstlane(t >> 6) * 64, w1 = min(w0 + 63, p.P - 1);
+  const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int qr0 = row0 + (wv >> 1) * 8, qc0 = col0 + (wv & 1) * 8;   // the quadrant's first pixel
+  const int r = qr0 + (lane >> 3), c = qc0 + (lane & 7);             // this lane's pixel
+  const bool live = r < p.ph && c < p.pw;
   u64 rel[NG];
   int anch[NG];      // lane l: anchor of detection g*64 + l (same round trip as its crop edges)
 #pragma unroll
   for (int g = 0; g < NG; ++g) { rel[g] = 0ull; anch[g] = 0; }
-  if (w0 < p.P) {
-    const int r0 = w0 / p.pw, r1 = w1 / p.pw;
-    int c0 = w0 - r0 * p.pw, c1 = w1 - r1 * p.pw;
-    if (r1 > r0) { c0 = 0; c1 = p.pw - 1; }
-    const float fr0 = (float)r0, fr1 = (float)r1, fc0 = (float)c0, fc1 = (float)c1;
+  if (qr0 < p.ph && qc0 < p.pw) {
+    const float fr0 = (float)qr0, fr1 = (float)min(qr0 + 7, p.ph - 1), fc0 = (float)qc0, fc1 = (float)min(qc0 + 7, p.pw - 1);
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
-      if (g * 64 < N) {
+      if (g * 64 < p.sel_rows) {
         const int n = g * 64 + lane;
-        const float4 cb = p.crop[(size_t)b * p.sel_rows + min(n, N - 1)];
-        if (p.anchor) anch[g] = p.anchor[(size_t)b * p.sel_rows + min(n, N - 1)];
+        const int nc = min(n, p.sel_rows - 1);
+        const float4 cb = p.crop[(size_t)b * p.sel_rows + nc];
+        if (p.anchor) anch[g] = p.anchor[(size_t)b * p.sel_rows + nc];
         const bool hit = (n < N) && (fc1 >= cb.x) && (fc0 < cb.y) && (fr1 >= cb.z) && (fr0 < cb.w);
         const u64 m = __ballot(hit);
         rel[g] = ((u64)(uint32_t)__builtin_amdgcn_readfirstlane((int)(m >> 32)) << 32) |
@@ -101,25 +105,31 @@ __global__ __launch_bounds__(YP_MASK_BLOCK) void mask_assemble_kernel(const Mask
       }
     }
   }
-  // Rows already zero-filled: a workgroup none of whose waves is touched by any detection has
-  // nothing to write.
+  // A workgroup none of whose waves is touched by any detection has nothing to write.
   u64 any_rel = 0ull;
 #pragma unroll
   for (int g = 0; g < NG; ++g) any_rel |= rel[g];
-  if (p.prezeroed && __syncthreads_or(any_rel != 0ull) == 0) return;
+  if (__syncthreads_or(any_rel != 0ull) == 0) return;
 
   float pr[YP_MASK_DIM];
   {
     // The transpose goes through LDS two quads at a time (four passes over a 12 KiB buffer instead of one
     // pass over 36 KiB): LDS is what limits residency here, and with it the waves that hide each
-    // other's latencies.
+    // other's latencies.  The LDS row of a pixel is the id of the thread that owns it.
+    // Thread t loaded the pixels (2i + (t >> 7), (t & 127) >> 3) of the tile: owner = quadrant << 6 | row in the
+    // quadrant << 3 | column in it.  Everything but the row's part is the same for all eight loads.
+    const int lcol = (t & 127) >> 3;
+    const int own0 = ((lcol >> 3) << 6) | (lcol & 7);
 #pragma unroll
     for (int q = 0; q < YP_MASK_DIM / 8; ++q) {
       if (q > 0) __syncthreads();            // the previous pass has been read
       if (((t & 7) >> 1) == q) {
 #pragma unroll
-        for (int i = 0; i < YP_MASK_DIM / 4; ++i)
-          sproto[(i * (YP_MASK_BLOCK / 8) + (t >> 3)) * YP_MASK_ROW4 + (t & 1)] = make_float4(x[i].x, x[i].y, x[i].z, x[i].w);
+        for (int i = 0; i < YP_MASK_DIM / 4; ++i) {
+          const int lrow = 2 * i + (t >> 7);
+          const int own = own0 | ((lrow >> 3) << 7) | ((lrow & 7) << 3);
+          sproto[own * YP_MASK_ROW4 + (t & 1)] = make_float4(x[i].x, x[i].y, x[i].z, x[i].w);
+        }
       }
       __syncthreads();
       const float4 lo = sproto[t * YP_MASK_ROW4 + 0], hi = sproto[t * YP_MASK_ROW4 + 1];
@@ -127,69 +137,32 @@ __global__ __launch_bounds__(YP_MASK_BLOCK) void mask_assemble_kernel(const Mask
       pr[8 * q + 4] = hi.x; pr[8 * q + 5] = hi.y; pr[8 * q + 6] = hi.z; pr[8 * q + 7] = hi.w;
     }
   }
-  const int r = pix / p.pw;
   const float frow = live ? (float)r : -1.0f;                  // tf.range(..., dtype=float32), utils/utils.py:119-120
-  const float fcol = live ? (float)(pix - r * p.pw) : -1.0f;
+  const float fcol = live ? (float)c : -1.0f;
 
   // Row addresses are a wave-uniform base (SGPRs) plus a 32-bit lane offset (global_store saddr form)
-  float* orow = p.masks + ((size_t)b * p.max_dets) * p.P + base_pix;
-  uint8_t* brow = p.bitmaps ? p.bitmaps + ((size_t)b * p.max_dets) * p.P + base_pix : nullptr;
+  float* orow = p.masks + ((size_t)b * p.max_dets) * p.P;
+  uint8_t* brow = p.bitmaps ? p.bitmaps + ((size_t)b * p.max_dets) * p.P : nullptr;
   typedef const __attribute__((address_space(4))) float cfloat;
   cfloat* const crop_c = (cfloat*)(p.crop + (size_t)b * p.sel_rows);
   cfloat* const coef_c = (cfloat*)(p.coef + (size_t)b * (p.anchor ? (size_t)p.A : (size_t)p.sel_rows) * YP_MASK_DIM);
 
   // The CU's scalar unit is shared by all its waves, and a loop over every detection with a test and
-  // a branch per row is bound by it (measured: ~36 of 62 us with no memory traffic at all).  So only
-  // the rows whose bit is set (found with ctz) are visited at all.
-  const uint32_t voff = (uint32_t)t * 4u;
+  // a branch per row is bound by it.  So only the rows whose bit is set (found with ctz) are visited at all.
+  const int pix = live ? r * p.pw + c : 0;
+  const uint32_t voff = (uint32_t)pix * 4u;
   const uint32_t rstride = (uint32_t)p.P * 4u;     // yp_create bounds sel_rows * P * 4 below 2^32
   const bool plain = !NT_STORE && brow == nullptr;
-  //   pass Z  (only when the rows were not zero-filled beforehand) every row gets zeros: one store +
-  //           one vector add per row, nothing scalar but the loop
-  //   pass R  only the rows whose bit is set are computed and stored again, after the zeros have
-  //           been acknowledged (vmcnt(0), plus a barrier where another wave wrote them)
-  const int lane_ = t & 63;
-  const bool wide = plain && (p.P & 3) == 0 && ((uintptr_t)p.masks & 15u) == 0;
-  if (p.prezeroed) {
-    // nothing: the rows are zero already and only the detections that touch this wave are rewritten
-  } else if (wide) {
-    // the workgroup's 256 pixels of a row are 1 KiB: one 16-byte store per lane zeroes a whole row
-    // segment (eight full lines), wave w taking rows w, w+4, ...  The rows are then rewritten by the
-    // waves that own their pixels, so these stores must have completed first.
-    const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
-    if (lane_ < (npx >> 2)) {
-      uint32_t vo = (uint32_t)lane_ * 16u + (uint32_t)wv * rstride;
-      const nat4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
-      const int nz = p.zero_pad ? p.max_dets : N;   // tf.zeros rows of detection.py:68 included
-      for (int n = wv; n < nz; n += YP_MASK_BLOCK / 64, vo += (YP_MASK_BLOCK / 64) * rstride)
-        asm volatile("global_store_dwordx4 %0, %1, %2" ::"v"(vo), "v"(zero4), "s"(orow) : "memory");
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-  } else if (live) {
-    if (plain) {
-      uint32_t vo = voff;
-      const float zero = 0.0f;
-      for (int n = 0; n < N; ++n, vo += rstride)
-        asm volatile("global_store_dword %0, %1, %2" ::"v"(vo), "v"(zero), "s"(orow) : "memory");
-    } else {
-      for (int n = 0; n < N; ++n) {
-        if (NT_STORE) __builtin_nontemporal_store(0.0f, orow + (size_t)n * p.P + t); else orow[(size_t)n * p.P + t] = 0.0f;
-        if (brow) brow[(size_t)n * p.P + t] = 0.0f > p.mask_threshold ? 1 : 0;               // train.py:497
-      }
-    }
-  }
-  // per-wave zero pass: this wave rewrites its own addresses below; its zeros are acknowledged first
-  if (!p.prezeroed && !wide) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
   for (int g = 0; g < NG; ++g) {
-    u64 w = g * 64 < N ? rel[g] : 0ull;        // wave-uniform
+    u64 w = rel[g];                            // wave-uniform
     while (w != 0ull) {
       const int n = g * 64 + __builtin_ctzll(w);
       w &= w - 1ull;
       // Crop edges and coefficients of detection n are wave-uniform and were written by the previous
-      // kernel: read them through the constant address space so they arrive by scalar loads (SGPRs,
-      // scalar cache) and never wait on this wave's own outstanding vector stores.
+      // kernel (the coefficients by the network): read them through the constant address space so they
+      // arrive by scalar loads (SGPRs, scalar cache) and never wait on this wave's own outstanding vector
+      // stores.
       float4 cb;
       cb.x = crop_c[4 * n + 0]; cb.y = crop_c[4 * n + 1]; cb.z = crop_c[4 * n + 2]; cb.w = crop_c[4 * n + 3];
       // the detection's coefficient row: by its anchor, straight from pred_mask_coef (a wave-uniform index: the
@@ -204,34 +177,26 @@ __global__ __launch_bounds__(YP_MASK_BLOCK) void mask_assemble_kernel(const Mask
       for (int k = 0; k < YP_MASK_DIM; ++k) acc = __builtin_fmaf(pr[k], cf[k], acc);       // detection.py:89
       const float sg = yp_sigmoid(acc);                                                    // detection.py:90
       const float v = yp_clip(in ? sg : 0.0f, 0.0f, 1.0f);                                  // utils.py:133, L105
-      if (live) {
+      // only the pixels inside the box are written (the others hold their zeros): in a tile that is most of
+      // the lanes, and the neighbouring tiles write the rest of the cache line
+      if (in) {
         if (plain) {
           const uint32_t vo = voff + (uint32_t)n * rstride;
           asm volatile("global_store_dword %0, %1, %2" ::"v"(vo), "v"(v), "s"(orow) : "memory");
         } else {
-          if (NT_STORE) __builtin_nontemporal_store(v, orow + (size_t)n * p.P + t); else orow[(size_t)n * p.P + t] = v;
-          if (brow) brow[(size_t)n * p.P + t] = v > p.mask_threshold ? 1 : 0;                // train.py:497
+          if (NT_STORE) __builtin_nontemporal_store(v, orow + (size_t)n * p.P + pix); else orow[(size_t)n * p.P + pix] = v;
+          if (brow) brow[(size_t)n * p.P + pix] = v > p.mask_threshold ? 1 : 0;                // train.py:497
         }
       }
     }
   }
-  if (p.zero_pad && live && !wide && !p.prezeroed) {   // tf.zeros rows of detection.py:68 (the wide zero pass has written them already)
-    float* const out_img = p.masks + (size_t)b * p.max_dets * p.P;
-    uint8_t* const bit_img = p.bitmaps ? p.bitmaps + (size_t)b * p.max_dets * p.P : nullptr;
-    for (int n = N; n < p.max_dets; ++n) {
-      const size_t o = (size_t)n * p.P + pix;
-      out_img[o] = 0.0f;
-      if (bit_img) bit_img[o] = 0;
-    }
-  }
 }
 
-// Does this batch take the separate zero-fill (1: extra workgroups of the NMS launch, nms.hip
-// fill_block) or mask_assemble's fused pass Z (0)?  The linear fill is the form in which HBM takes
-// writes fastest, it does not depend on the NMS, and the NMS workgroups it shares a launch with are
-// latency-bound and leave HBM idle; the fused pass (1 KiB pieces at a row stride) only keeps up while
-// the whole output set lives in the 256 MiB Infinity Cache because the caller rewrites one buffer.
-// The separate fill is the default; the fused pass stays selectable (YP_TUNE_PREFILL=0).
+// Are the zeros written by extra workgroups of the NMS launch (1, the default: the fill depends on nothing the
+// NMS computes, HBM is idle while those latency-bound workgroups wait on their loads, and riding in the same
+// launch costs no second stream and no events) or by a fill launch of its own just before mask_assemble
+// (0: YP_TUNE_PREFILL=0)?  Either way it is the same linear fill (nms.hip fill_block) - the form in which HBM
+// takes writes fastest - over the same rows.
 int yp_mask_prefill(const yp_handle* h, int batch) {
   (void)batch;
   return h->tune.prefill >= 0 ? h->tune.prefill != 0 : 1;
@@ -247,26 +212,37 @@ int yp_mask_fill_rows(const yp_handle* h) {
   return rows;
 }
 
-hipError_t yp_launch_mask_assemble(const yp_handle* h, int batch, const float* proto, const float* pred_mask_coef,
-                                   const int32_t* num_det, float* det_masks, uint8_t* det_bitmaps, hipStream_t st) {
-  MaskArgs a;
-  a.proto = proto; a.coef = pred_mask_coef; a.anchor = h->s.sel_anchor; a.A = h->cfg.num_anchors;
-  a.crop = h->s.crop; a.num_det = num_det;
-  a.masks = det_masks; a.bitmaps = det_bitmaps;
-  a.P = h->cfg.proto_h * h->cfg.proto_w; a.pw = h->cfg.proto_w;
-  a.max_dets = h->cfg.max_dets; a.sel_rows = h->sel_rows; a.zero_pad = h->cfg.zero_pad_masks;
-  a.prezeroed = yp_mask_prefill(h, batch) ? 1 : 0;
-  a.mask_threshold = h->cfg.mask_threshold;
-  const int bpi = (a.P + YP_MASK_BLOCK - 1) / YP_MASK_BLOCK;
+static hipError_t launch_mask_kernel(const MaskArgs& a, int batch, int ph, bool nt, hipStream_t st) {
+  const int tiles_y = (ph + YP_MASK_TILE - 1) / YP_MASK_TILE;
+  const int bpi = a.tiles_x * tiles_y;
   const int by_xcd = batch >= 8 ? 1 : 0;
   const dim3 grid(by_xcd ? 8 * ((batch + 7) / 8) * bpi : batch * bpi);
   // Default-policy stores: the zeros the fill has just written usually still sit (dirty) in the
   // Infinity Cache, and these stores overwrite them there.  (tune.mask_nt: non-temporal instead.)
   const int ng = (a.sel_rows + 63) / 64;
 #define YP_MASK_LAUNCH(NT, NG) hipLaunchKernelGGL((mask_assemble_kernel<NT, NG>), grid, dim3(YP_MASK_BLOCK), 0, st, a, bpi, batch, by_xcd)
-  if (h->tune.mask_nt) { if (ng <= 1) YP_MASK_LAUNCH(true, 1); else if (ng <= 2) YP_MASK_LAUNCH(true, 2); else YP_MASK_LAUNCH(true, 4); }
+  if (nt) { if (ng <= 1) YP_MASK_LAUNCH(true, 1); else if (ng <= 2) YP_MASK_LAUNCH(true, 2); else YP_MASK_LAUNCH(true, 4); }
   else { if (ng <= 1) YP_MASK_LAUNCH(false, 1); else if (ng <= 2) YP_MASK_LAUNCH(false, 2); else YP_MASK_LAUNCH(false, 4); }
+#undef YP_MASK_LAUNCH
   return hipGetLastError();
+}
+
+hipError_t yp_launch_mask_assemble(const yp_handle* h, int batch, const float* proto, const float* pred_mask_coef,
+                                   const int32_t* num_det, float* det_masks, uint8_t* det_bitmaps, hipStream_t st) {
+  if (!yp_mask_prefill(h, batch)) {   // the zeros did not ride in the NMS launch
+    const hipError_t e = yp_launch_fill(det_masks, det_bitmaps, (long long)h->cfg.proto_h * h->cfg.proto_w, yp_mask_fill_rows(h),
+                                        h->cfg.max_dets, batch, st);
+    if (e != hipSuccess) return e;
+  }
+  MaskArgs a;
+  a.proto = proto; a.coef = pred_mask_coef; a.anchor = h->s.sel_anchor; a.A = h->cfg.num_anchors;
+  a.crop = h->s.crop; a.num_det = num_det;
+  a.masks = det_masks; a.bitmaps = det_bitmaps;
+  a.P = h->cfg.proto_h * h->cfg.proto_w; a.pw = h->cfg.proto_w; a.ph = h->cfg.proto_h;
+  a.tiles_x = (a.pw + YP_MASK_TILE - 1) / YP_MASK_TILE;
+  a.max_dets = h->cfg.max_dets; a.sel_rows = h->sel_rows;
+  a.mask_threshold = h->cfg.mask_threshold;
+  return launch_mask_kernel(a, batch, a.ph, h->tune.mask_nt != 0, st);
 }
 
 // ---- the same kernel for the training loss (the gradients: loss_grad.hip) ----------
@@ -299,17 +275,16 @@ hipError_t yp_launch_crop_edges(int total, int ph, int pw, int img_h, int img_w,
 hipError_t yp_launch_loss_masks(int batch, int rows, int ph, int pw, int img_h, int img_w, int use_crop, const float* proto,
                                 const float* coef, const float* boxes, const int32_t* num_rows, float* crop_ws, float* out_masks,
                                 hipStream_t st) {
-  const hipError_t e = yp_launch_crop_edges(batch * rows, ph, pw, img_h, img_w, use_crop, boxes, crop_ws, st);
+  hipError_t e = yp_launch_crop_edges(batch * rows, ph, pw, img_h, img_w, use_crop, boxes, crop_ws, st);
+  if (e != hipSuccess) return e;
+  e = yp_launch_fill(out_masks, nullptr, (long long)ph * pw, rows, rows, batch, st);   // rows >= num_rows[b] stay zeros (L273 pads nothing; the caller slices)
   if (e != hipSuccess) return e;
   MaskArgs a;
   a.proto = proto; a.coef = coef; a.anchor = nullptr; a.A = 0;
   a.crop = reinterpret_cast<const float4*>(crop_ws); a.num_det = num_rows;
   a.masks = out_masks; a.bitmaps = nullptr;
-  a.P = ph * pw; a.pw = pw; a.max_dets = rows; a.sel_rows = rows; a.zero_pad = 1; a.prezeroed = 0;
+  a.P = ph * pw; a.pw = pw; a.ph = ph; a.tiles_x = (pw + YP_MASK_TILE - 1) / YP_MASK_TILE;
+  a.max_dets = rows; a.sel_rows = rows;
   a.mask_threshold = -1.0f;
-  const int bpi = (a.P + YP_MASK_BLOCK - 1) / YP_MASK_BLOCK;
-  const int by_xcd = batch >= 8 ? 1 : 0;
-  const dim3 grid(by_xcd ? 8 * ((batch + 7) / 8) * bpi : batch * bpi);
-  hipLaunchKernelGGL((mask_assemble_kernel<false, 4>), grid, dim3(YP_MASK_BLOCK), 0, st, a, bpi, batch, by_xcd);
-  return hipGetLastError();
+  return launch_mask_kernel(a, batch, ph, false, st);
 }

@@ -66,6 +66,9 @@ struct NmsArgs {
   float* fill_masks;          // [B,max_dets,P] or null: rows [0, fill_rows) of every image get zeros
   uint8_t* fill_bitmaps;      // [B,max_dets,P] or null
   long long fill_P;           // proto_h * proto_w
+  long long fill_first;       // the launch's fill workgroups take the chunks [fill_first, fill_last) between them
+  long long fill_last;        // (the whole fill; a range so that a launch can carry a part of it)
+  int fill_wgs;               // number of fill workgroups in the launch (fill workgroup i takes chunks first + i, + fill_wgs, ...)
   int fill_rows, batch;
 
   float nms_thresh, img_h, img_w, proto_h, proto_w;
@@ -708,6 +711,15 @@ __device__ __forceinline__ void fill_block(const NmsArgs& p, long long ch) {
   }
 }
 
+// A fill workgroup of an NMS launch takes every fill_wgs-th chunk of the launch's range.  (Waiting for a chunk's
+// acknowledgements before the next chunk - to bound the zeros in flight - slows the fill down and does not make the
+// loads of the NMS workgroups beside it any faster: the stores are acknowledged by the L2, and what a load waits
+// for under the fill is the memory side; 32 KiB chunks with waits: 180 us per launch against 56.)
+template <int THREADS>
+__device__ __forceinline__ void fill_loop(const NmsArgs& p, int wg) {
+  for (long long ch = p.fill_first + wg; ch < p.fill_last; ch += p.fill_wgs) fill_block<THREADS>(p, ch);
+}
+
 // Cross-class mode: one workgroup per image (detection.py:181-209).
 // One round trip brings the lengths of the image's lists and the first YP_CC_PRE entries per thread (keys and
 // boxes, 4096 per image); the top_k selection runs on the keys; then every thread that holds one of the selected
@@ -723,7 +735,7 @@ __global__ __launch_bounds__(THREADS) void cc_nms_kernel(const NmsArgs p) {
   __shared__ int s_cnt[YP_NLISTS];
   const int t = threadIdx.x;
   if ((int)blockIdx.x >= p.nms_blocks) {   // workgroup-uniform
-    fill_block<THREADS>(p, (long long)blockIdx.x - p.nms_blocks);
+    fill_loop<THREADS>(p, (int)blockIdx.x - p.nms_blocks);
     return;
   }
   if (t == 0) sh.hist = s_hist;            // (published by the barriers of block_sum below)
@@ -801,7 +813,13 @@ __global__ __launch_bounds__(THREADS) void cc_nms_kernel(const NmsArgs p) {
 // that the hand-off needs no agent-scope release - a release writes back every dirty line of the
 // XCD's L2, and with the mask zero-fill running in the same launch that is megabytes per fence
 // (measured: 208 us per launch with release fences against ~50 with write-through stores).
-// tests/test_abi.py disassembles the built library and checks that these stores carry sc1.
+// tests/test_abi.py disassembles the built library and checks that these stores carry sc1 and that the
+// arrival is an atomic followed by an invalidate: the C++ memory model promises nothing for this pattern.
+// (Tried in round 3: the class groups and the images' selections as TWO launches, each with a part of the fill -
+// plain stores, no protocol.  57.7 us against 55.4 at config 2 and 100 against 91 at config 4: the selections'
+// ~16 us under the fill's load no longer overlap the groups, and a launch boundary behind a fill costs the L2's
+// write-back.  A head start of 2.5 us for the selections' loads - they return in 2 us then, against 10-16 once
+// the zero stream runs - changed nothing in total.)
 __device__ __forceinline__ void store_wt(u64* p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void store_wt(int32_t* p, int32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void store_wt(float4* p, const float4 v) {
@@ -1156,17 +1174,27 @@ __device__ __forceinline__ void final_select_body(const NmsArgs& p, int b, Group
   const int pg = sl >> sft, pq = sl & (lpp - 1);
   const u64* const pl = src.base + (size_t)pg * p.gcap;
   const float4* const plb = p.pool_box + ((size_t)b * p.ngroups + pg) * p.gcap;
+  // (only slots below `want` can hold anything: a group pools at most its best `want` survivors)
+  const int want = min(min(p.max_dets, YP_SORT_MAX), p.gcap);
   float4 preb[YP_POOL_PRE_BOX];
 #pragma unroll
   for (int u = 0; u < YP_POOL_PRE; ++u) {
-    const int i = min(pq + u * lpp, p.gcap - 1);
+    const int i = min(pq + u * lpp, want - 1);
     src.pre[u] = pl[i];
     if (u < YP_POOL_PRE_BOX) preb[u] = plb[i];
   }
+#ifdef YP_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  STAMP(12);
+#endif
   int cnt = 0;
   if (t < p.ngroups) cnt = p.pool_count[(size_t)b * p.ngroups + t];
   int part = 0;
   for (int i = t; i < p.parts; i += THREADS) part += p.seg_surv[(size_t)b * p.parts + i];
+#ifdef YP_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  STAMP(13);
+#endif
   if (t < 64) {                                   // ngroups <= 16: exclusive prefix of the lengths in the first wave
     const int incl = wave_incl_scan(cnt);
     if (t < p.ngroups) start[t + 1] = incl;
@@ -1222,10 +1250,15 @@ __device__ __forceinline__ void final_select_body(const NmsArgs& p, int b, Group
 template <int THREADS>
 __global__ __launch_bounds__(THREADS, YP_GROUP_MIN_WAVES) void group_nms_kernel(const NmsArgs p) {
   if ((int)blockIdx.x >= p.nms_blocks) {   // workgroup-uniform
-    fill_block<THREADS>(p, (long long)blockIdx.x - p.nms_blocks);
+    fill_loop<THREADS>(p, (int)blockIdx.x - p.nms_blocks);
     return;
   }
   __shared__ GroupShared gs;
+#ifdef YP_EXP_NMS_NOP   // experiment build (timing only, wrong results): how long does the fill take with no NMS beside it?
+  if (threadIdx.x == 0 && (int)blockIdx.x % p.ngroups == 0) p.num_det[(int)blockIdx.x / p.ngroups] = 0;
+  if (threadIdx.x == 0) p.lcount[((size_t)blockIdx.x / p.ngroups * YP_NLISTS + blockIdx.x % p.ngroups) * YP_CNT_STRIDE] = 0;
+  return;
+#endif
   const int b = (int)blockIdx.x / p.ngroups, g = (int)blockIdx.x - b * p.ngroups;
   group_nms_body<THREADS>(p, b, g, gs);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pool stores have completed
@@ -1244,6 +1277,25 @@ __global__ __launch_bounds__(THREADS, YP_GROUP_MIN_WAVES) void group_nms_kernel(
   __syncthreads();
   if (!gs.last) return;
   final_select_body<THREADS>(p, b, gs);
+}
+
+// The zero-fill alone (callers with no NMS launch to carry it: yp_assemble_masks; YP_TUNE_PREFILL=0).
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void fill_kernel(const NmsArgs p) { fill_loop<THREADS>(p, (int)blockIdx.x); }
+
+hipError_t yp_launch_fill(float* masks, uint8_t* bitmaps, long long P, int fill_rows, int max_dets, int batch, hipStream_t st) {
+  constexpr int T = YP_GROUP_THREADS;
+  NmsArgs a = {};
+  a.fill_masks = masks; a.fill_bitmaps = masks ? bitmaps : nullptr;
+  a.fill_P = P; a.fill_rows = fill_rows; a.max_dets = max_dets; a.batch = batch; a.fill_first = 0;
+  long long nfill = 0;
+  if (a.fill_masks) nfill += fill_chunks_per_image<T>(P, fill_rows, 4) * batch;
+  if (a.fill_bitmaps) nfill += fill_chunks_per_image<T>(P, fill_rows, 1) * batch;
+  if (nfill == 0) return hipSuccess;
+  a.fill_first = 0; a.fill_last = nfill;
+  a.fill_wgs = (int)(nfill < 4096 ? nfill : 4096);   // (alone in its launch: nothing queues behind the zeros)
+  hipLaunchKernelGGL((fill_kernel<T>), dim3((unsigned)a.fill_wgs), dim3(T), 0, st, a);
+  return hipGetLastError();
 }
 
 static NmsArgs make_args(const yp_handle* h, int batch, const float* pred_offset, const float* priors,
@@ -1274,6 +1326,10 @@ static NmsArgs make_args(const yp_handle* h, int batch, const float* pred_offset
   return a;
 }
 
+#ifndef YP_FILL_WGS_PER_CU
+#define YP_FILL_WGS_PER_CU 3   // fill workgroups of an NMS launch per compute unit (each walks its share of the chunks)
+#endif
+
 // NMS (both modes; in per-class mode including the final selection) plus, when fill_masks is given,
 // the zero-fill of rows [0, fill_rows) of every image's masks (and bitmaps) as extra workgroups.
 hipError_t yp_launch_nms(const yp_handle* h, int batch, const float* pred_offset, const float* priors, float* det_boxes,
@@ -1283,22 +1339,23 @@ hipError_t yp_launch_nms(const yp_handle* h, int batch, const float* pred_offset
   a.arrive = h->s.arrive;
   a.fill_masks = fill_masks; a.fill_bitmaps = fill_masks ? fill_bitmaps : nullptr;
   a.fill_P = (long long)h->cfg.proto_h * h->cfg.proto_w; a.fill_rows = fill_rows; a.batch = batch;
+  const long long max_wgs = (long long)h->num_cus * YP_FILL_WGS_PER_CU;
   if (h->cfg.nms_mode == YP_NMS_CROSS_CLASS) {
     constexpr int T = YP_CC_THREADS;
     a.nms_blocks = batch;
     long long nfill = 0;
     if (a.fill_masks) nfill += fill_chunks_per_image<T>(a.fill_P, fill_rows, 4) * batch;
     if (a.fill_bitmaps) nfill += fill_chunks_per_image<T>(a.fill_P, fill_rows, 1) * batch;
-    if (a.nms_blocks + nfill > 0x7fffffffll) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((cc_nms_kernel<T>), dim3((unsigned)(a.nms_blocks + nfill)), dim3(T), 0, st, a);
+    a.fill_first = 0; a.fill_last = nfill; a.fill_wgs = (int)(nfill < max_wgs ? nfill : max_wgs);
+    hipLaunchKernelGGL((cc_nms_kernel<T>), dim3((unsigned)(a.nms_blocks + a.fill_wgs)), dim3(T), 0, st, a);
   } else {
     constexpr int T = YP_GROUP_THREADS;
     a.nms_blocks = batch * a.ngroups;
     long long nfill = 0;
     if (a.fill_masks) nfill += fill_chunks_per_image<T>(a.fill_P, fill_rows, 4) * batch;
     if (a.fill_bitmaps) nfill += fill_chunks_per_image<T>(a.fill_P, fill_rows, 1) * batch;
-    if (a.nms_blocks + nfill > 0x7fffffffll) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((group_nms_kernel<T>), dim3((unsigned)(a.nms_blocks + nfill)), dim3(T), 0, st, a);
+    a.fill_first = 0; a.fill_last = nfill; a.fill_wgs = (int)(nfill < max_wgs ? nfill : max_wgs);
+    hipLaunchKernelGGL((group_nms_kernel<T>), dim3((unsigned)(a.nms_blocks + a.fill_wgs)), dim3(T), 0, st, a);
   }
   return hipGetLastError();
 }

@@ -195,7 +195,11 @@ __global__ __launch_bounds__(YP_WAVE, YP_SF_MIN_WAVES) void score_filter_kernel(
         const int anchor = min(yp_seg_key_anchor(key), p.A - 1);
         const float4 pr = p.priors[anchor], of = p.off[(size_t)b * p.A + anchor];
         int lst;
+#ifdef YP_EXP_ONE_ATOMIC   // experiment build (timing only, wrong results): what do the per-list atomics cost?
+        if (true) {
+#else
         if (MODE == YP_NMS_CROSS_CLASS) {
+#endif
           lst = part & (YP_NLISTS - 1);
         } else {
           // (c - 1) % ngroups without the integer division: (x + 0.5) / n is at least 0.5 / n away from an
