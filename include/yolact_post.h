@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define YP_VERSION 210 /* 0.2.1 */
+#define YP_VERSION 300 /* 0.3.0 */
 
 enum {
   YP_OK = 0,
@@ -129,7 +129,10 @@ int yp_run(yp_handle* h, int32_t batch,
  * configuration of which a single image does not fit is rejected with YP_EINVAL (per-class mode
  * needs about 8 * num_anchors * min(num_classes-1, 1/conf_thresh + 1) bytes per image).  It calls no
  * hipMalloc / hipFree, creates no stream or event and does not synchronise.  Every call on a GPU uses that GPU's one array: calls
- * that overlap on one GPU (two streams, two threads) race and give wrong results - serialise them. */
+ * that overlap on one GPU (two streams, two threads) race and give wrong results - serialise them.
+ * The FIRST call with a (device, configuration) pair makes that pair's launch plan (attribute / occupancy queries,
+ * the YP_TUNE_* environment, and once per device hipGetSymbolAddress): make it eagerly, outside any graph capture.
+ * The plans of the last four configurations per device are remembered; later calls with them query nothing. */
 #define YP_STATIC_SCRATCH_BYTES (64u << 20)
 int yp_run_static(const yp_config* cfg, int32_t batch,
                   const float* pred_offset, const float* pred_cls, const float* pred_mask_coef,
@@ -181,13 +184,27 @@ int64_t yp_make_priors(int32_t img_h, int32_t img_w, int32_t num_levels, const i
  *   rle_len   [batch,max_dets] int32: number of counts (0 for rows >= num_det).  Only the first
  *             rle_cap counts are stored; rle_len > rle_cap tells the caller to retry with more room
  *             (out_h*out_w + 1 always suffices).
- * Limits: mask_h <= 512, out_h <= 4096.  Asynchronous on hip_stream; allocates nothing. */
+ * Limits: mask_h <= 512, out_h <= 4096.  Output sizes smaller than the mask are resized as cv::resize's
+ * INTER_LINEAR does (two taps, no anti-aliasing) - EXCEPT mask_h == 2*out_h && mask_w == 2*out_w, where
+ * cv::resize silently switches to INTER_AREA: that one size pair is rejected with YP_EINVAL.
+ * Asynchronous on hip_stream; allocates nothing. */
 enum { YP_RESIZE_THEN_THRESHOLD = 0, YP_THRESHOLD_THEN_RESIZE = 1 };
 int yp_masks_to_rle(int32_t device_id, int32_t batch, int32_t max_dets, int32_t mask_h, int32_t mask_w,
                     const float* det_masks, const int32_t* num_det,
                     int32_t out_h, int32_t out_w, float threshold, int32_t order,
                     uint8_t* bitmaps, uint32_t* rle_counts, int32_t* rle_len, int32_t rle_cap,
                     void* hip_stream);
+
+/* The same with every image's OWN output size, as coco_eval.py:112-137 does it (`_h, _w` of the original image
+ * per batch element): out_hw = HOST array [batch][2] of (height, width).  One call for a batch of differently
+ * sized originals (launches of up to 32 images each, the sizes travel in the kernels' argument blocks: still no
+ * allocation and no copy).  No bitmaps here; rle_counts / rle_len as above (rle_cap >= max(out_h*out_w) + 1
+ * always suffices). */
+int yp_masks_to_rle_sized(int32_t device_id, int32_t batch, int32_t max_dets, int32_t mask_h, int32_t mask_w,
+                          const float* det_masks, const int32_t* num_det,
+                          const int32_t* out_hw, float threshold, int32_t order,
+                          uint32_t* rle_counts, int32_t* rle_len, int32_t rle_cap,
+                          void* hip_stream);
 
 /* ---- mask assembly of the training loss (forward - the gradients follow below) ----
  * loss/loss_yolact.py:239-253 (YOLACTLoss._loss_mask): mask_p = sigmoid(proto_out[i] @ pos_coef^T),
@@ -215,7 +232,8 @@ int yp_assemble_masks(int32_t device_id, int32_t batch, int32_t rows, int32_t pr
  *   grad_proto [batch,ph,pw,32]   grad_coef [batch,rows,32]
  *   workspace: yp_assemble_masks_backward_workspace(batch, rows, proto_h) bytes of device memory the caller
  *              provides (= 4*batch*rows*(4 + 32*proto_h): the crop edges and grad_coef per pixel row)
- * All device pointers; proto, coef, boxes, workspace, grad_proto 16-byte aligned; proto_w <= 1024;
+ * All device pointers; proto, coef, boxes, workspace, grad_proto 16-byte aligned; proto_w <= 1000 (a prototype row
+ * must fit in LDS; checked before anything is launched);
  * asynchronous on hip_stream; allocates nothing. */
 int64_t yp_assemble_masks_backward_workspace(int32_t batch, int32_t rows, int32_t proto_h);
 int yp_assemble_masks_backward(int32_t device_id, int32_t batch, int32_t rows, int32_t proto_h, int32_t proto_w,

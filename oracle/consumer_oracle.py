@@ -44,12 +44,21 @@ def _linear_coeffs(src: int, dst: int):
     return s, f
 
 
+def _no_area_substitution(h, w, out_h, out_w):
+    """cv::resize: `interpolation == INTER_LINEAR && is_area_fast && iscale_x == 2 && iscale_y == 2` -> INTER_AREA
+    (imgproc/src/resize.cpp).  Its float 2x2 average sums in a SIMD-width dependent order; not restated - the
+    product rejects this size pair too."""
+    if h == 2 * out_h and w == 2 * out_w:
+        raise ValueError("exact 2x decimation in both axes: cv::resize uses INTER_AREA there (not restated)")
+
+
 def resize_linear_f32(src: np.ndarray, out_h: int, out_w: int) -> np.ndarray:
     """cv2.resize(src, (out_w, out_h)) for a float32 single-channel image, INTER_LINEAR."""
     src = np.ascontiguousarray(src, dtype=np.float32)
     h, w = src.shape
     if (h, w) == (out_h, out_w):
         return src.copy()                                         # cv::resize copies when the sizes agree
+    _no_area_substitution(h, w, out_h, out_w)
     one = np.float32(1.0)
     sx, fx = _linear_coeffs(w, out_w)
     left = sx < 0
@@ -72,6 +81,7 @@ def resize_linear_u8(src: np.ndarray, out_h: int, out_w: int) -> np.ndarray:
     h, w = src.shape
     if (h, w) == (out_h, out_w):
         return src.copy()
+    _no_area_substitution(h, w, out_h, out_w)
     one = np.float32(1.0)
     scale = np.float32(INTER_RESIZE_COEF_SCALE)
     sx, fx = _linear_coeffs(w, out_w)
@@ -198,5 +208,5 @@ def export_detections(result: dict, image_ids, orig_hw, threshold: float = 0.5, 
             rle = {'size': [int(_h), int(_w)], 'counts': rle_to_string(rle_counts(bm))}   # L136-137
             _y1, _x1, _y2, _x2 = (int(v) for v in det_boxes[i].astype(int))            # L139-140
             annotations.append({"image_id": image_id, "category_id": int(det_classes[i]), "segmentation": rle,
-                                "score": float(det_scores[i]), "_box_pixels": [_y1, _x1, _y2, _x2]})
+                                "score": float(det_scores[i])})                        # L150-155: these four keys
     return annotations

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     assert set(syms) == set(_lib.EXPORTS), (syms, _lib.EXPORTS)
     for s in syms:
         assert hasattr(L, s), s
-    assert L.yp_version() == 210
+    assert L.yp_version() == 300
 
 
 def test_config_struct_matches_header():
@@ -158,3 +158,70 @@ def test_pair_enumeration_used_by_the_nms_kernels():
                         assert pr[0] < pr[1] and pr not in seen, (k, s, v)
                         seen.add(pr)
             assert len(seen) == k * (k - 1) // 2, (threads, k)
+
+
+def _disassemble_kernel(name_part):
+    """The gfx950 ISA of one kernel of the built library (llvm-objdump on a copy: it unpacks the offload bundles
+    next to the file it is given)."""
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("llvm-objdump not available")
+    from yolact_amd import _lib
+    with tempfile.TemporaryDirectory() as d:
+        so = shutil.copy(_lib.LIB_PATH, d)
+        subprocess.run([objdump, "--offloading", so], cwd=d, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        for co in sorted(glob.glob(os.path.join(d, "*gfx950"))):
+            dis = subprocess.run([objdump, "-d", co], check=True, capture_output=True, text=True).stdout
+            lines, take = [], False
+            for ln in dis.splitlines():
+                if ln.endswith(">:"):
+                    take = name_part in ln
+                elif take and "\t" in ln:
+                    lines.append(ln.split("//")[0].strip())
+            if lines:
+                return lines
+    raise AssertionError(f"no kernel matching {name_part} in the gfx950 code objects")
+
+
+def test_cross_workgroup_handoff_is_write_through_in_the_emitted_isa():
+    """csrc/nms.hip hands the class groups' pooled survivors to the image's last-arriving workgroup INSIDE one
+    launch: write-through stores, a drained wave, an agent-scope atomic on the arrival counter, and an invalidate
+    on the consumer's side.  The C++ memory model promises nothing for relaxed stores without a release, so what
+    the compiler emits is pinned here: a toolchain that lowers it differently fails the build
+    check instead of corrupting detections now and then."""
+    isa = _disassemble_kernel("group_nms_kernel")
+    wt8 = [l for l in isa if l.startswith("global_store_dwordx2") and " sc1" in l]
+    wt4 = [l for l in isa if l.startswith("global_store_dword ") and " sc1" in l]
+    assert len(wt8) >= 4, "the pool's keys and boxes (8-byte halves) must be stored with sc1 (write-through)"
+    assert len(wt4) >= 1, "pool_count must be stored with sc1 (write-through)"
+    plain8 = [l for l in isa if l.startswith("global_store_dwordx2") and " sc1" not in l]
+    assert not plain8, f"an 8-byte store of the class-group kernel lost its sc1: {plain8[:2]}"
+    at = [i for i, l in enumerate(isa) if l.startswith("global_atomic_add")]
+    assert len(at) == 1, "exactly one atomic: the arrival counter"
+    assert " sc0" in isa[at[0]], "the arrival add must return the old value"
+    before = isa[max(0, at[0] - 400):at[0]]
+    assert any(l.startswith("s_waitcnt vmcnt(0)") for l in before) and any(l.startswith("s_barrier") for l in before), \
+        "the stores are drained and the workgroup meets before it arrives"
+    after = isa[at[0]:at[0] + 60]
+    assert any(l.startswith("buffer_inv") and "sc1" in l for l in after), "the last arriver invalidates (acquire) before it reads the pools"
+
+
+def test_score_filter_buffer_loads_keep_their_offset_inside_the_range_check():
+    """the staging loads of score_filter go through a buffer descriptor of exactly the tile and
+    rely on the hardware's range check to fetch nothing past it.  gfx9-family hardware checks VGPR offset +
+    immediate only - an SGPR offset is outside the check - so every staging load must carry its whole offset in
+    the VGPR / immediate part: soffset 0, `offen`."""
+    import re
+    n = 0
+    for mode in ("ILi0E", "ILi1E"):                      # cross-class and per-class instantiations
+        isa = _disassemble_kernel("score_filter_kernel" + mode + "Li11ELb1E")
+        loads = [l for l in isa if l.startswith("buffer_load_dwordx4")]
+        assert len(loads) >= 11
+        for l in loads:
+            assert re.search(r"s\[\d+:\d+\], 0 offen", l), f"staging load with an SGPR offset: {l}"
+        n += len(loads)
+    assert n >= 22

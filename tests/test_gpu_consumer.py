@@ -152,7 +152,7 @@ def test_reference_sizes(src, dst, order):
 
 def test_end_to_end_detect_to_annotations():
     """Detect -> export_detections against the oracle chain (Detect oracle -> consumer oracle):
-    coco_eval.py:123-155's dicts, two images with different original sizes."""
+    coco_eval.py:123-155's dicts, two images with different original sizes - one resize + RLE call for both."""
     import torch
     from oracle import c_oracle
     from yolact_amd import Detect, consumer, synth
@@ -161,14 +161,97 @@ def test_end_to_end_detect_to_annotations():
     res = det(net, shp)
     torch.cuda.synchronize()
     orig = [(61, 47), (96, 130)]
-    got = consumer.export_detections(res, ["img0", 7], orig)
+    got, boxes = consumer.export_detections(res, ["img0", 7], orig, return_boxes=True)
     ref_det = c_oracle.detect(net, shp, top_k=15, nms_mode="cc", max_dets=300)
     ref = co.export_detections(ref_det, ["img0", 7], orig)
-    assert len(got) == len(ref) > 0
+    assert len(got) == len(ref) == len(boxes) > 0
     for g, r in zip(got, ref):
         assert g == r, (g, r)
     import json
     json.dumps(got)                                                  # coco_eval.py:158-159: it must serialise
+
+
+def test_export_detections_emits_exactly_the_reference_keys():
+    """coco_eval.py:150-155 appends {'image_id', 'category_id', 'segmentation', 'score'} and nothing else; the list
+    below is written out by hand from a Detect result built by hand (no oracle in between): image 0 has two
+    detections above the 0.05 score threshold of L123 - a 2x2 block and a full mask -, image 1 none."""
+    import torch
+    from yolact_amd import consumer
+    masks = np.zeros((2, 3, 4, 4), np.float32)
+    masks[0, 0, 1:3, 1:3] = 0.9
+    masks[0, 1] = 0.8
+    masks[0, 2] = 0.7                                   # score 0.04: below the threshold, never exported
+    res = {
+        "detection_masks": torch.from_numpy(masks).cuda(),
+        "detection_scores": torch.tensor([[0.9, 0.25, 0.04], [0.0, 0.0, 0.0]], dtype=torch.float32).cuda(),
+        "detection_classes": torch.tensor([[3.0, 17.0, 5.0], [0.0, 0.0, 0.0]], dtype=torch.float32).cuda(),
+        "detection_boxes": torch.tensor([[[0.25, 0.25, 0.75, 0.75], [0.0, 0.0, 1.0, 1.0], [0.0, 0.0, 0.5, 0.5]],
+                                         [[0.0] * 4] * 3], dtype=torch.float32).cuda(),
+    }
+    got, boxes = consumer.export_detections(res, [42, "b"], [(4, 4), (9, 5)], return_boxes=True)   # identity size: cv2.resize copies
+    # column-major runs of the 2x2 block in a 4x4 image: 5 zeros, 2 ones, 2 zeros, 2 ones, 5 zeros -> rleToString
+    expected = [
+        {"image_id": 42, "category_id": 3, "segmentation": {"size": [4, 4], "counts": "52203"}, "score": float(np.float32(0.9))},
+        {"image_id": 42, "category_id": 17, "segmentation": {"size": [4, 4], "counts": "0`0"}, "score": 0.25},
+    ]
+    assert got == expected
+    assert [sorted(d) for d in got] == [["category_id", "image_id", "score", "segmentation"]] * 2
+    assert boxes == [[1, 1, 3, 3], [0, 0, 4, 4]]
+    assert consumer.export_detections(res, [42, "b"], [(4, 4), (9, 5)]) == expected
+
+
+@pytest.mark.parametrize("order", ["resize_then_threshold", "threshold_then_resize"])
+def test_per_image_output_sizes_in_one_call(order):
+    """coco_eval.py:112-137: every image's masks go to that image's own (_h, _w).  yp_masks_to_rle_sized takes the
+    sizes of a whole batch (more images than one launch's argument block holds: 32) and must give, image by image,
+    what the uniform-size entry point gives for that size - enlarging, shrinking and identity sizes mixed."""
+    import torch
+    from yolact_amd import consumer
+    rng = np.random.default_rng(17)
+    B, N, h, w = 37, 3, 14, 19
+    masks = _blobs(rng, B, N, h, w)
+    masks[::5] = rng.random((len(range(0, B, 5)), N, h, w)).astype(np.float32)
+    nd = rng.integers(0, N + 1, B).astype(np.int32)
+    sizes = [(int(rng.integers(3, 90)), int(rng.integers(3, 120))) for _ in range(B)]
+    sizes[3] = (h, w)                                                 # identity
+    sizes[4] = (7, 19); sizes[5] = (14, 9)                            # half of ONE axis only: still INTER_LINEAR
+    sizes = [(oh + 1, ow) if (2 * oh, 2 * ow) == (h, w) else (oh, ow) for oh, ow in sizes]
+    m = torch.from_numpy(masks).cuda(); n = torch.from_numpy(nd).cuda()
+    r = consumer.masks_to_rle(m, n, sizes, order=order, rle_cap=64)    # small cap: the retry path too
+    torch.cuda.synchronize()
+    counts, lens = r["counts"].cpu().numpy().view(np.uint32), r["len"].cpu().numpy()
+    o = co.RESIZE_THEN_THRESHOLD if order == "resize_then_threshold" else co.THRESHOLD_THEN_RESIZE
+    for b in range(B):
+        ref = co.masks_to_rle(masks[b:b + 1], nd[b:b + 1], sizes[b][0], sizes[b][1], 0.5, o)[0]
+        for k in range(N):
+            if k < nd[b]:
+                assert lens[b, k] == ref[k][1].shape[0], (b, k, sizes[b])
+                assert np.array_equal(counts[b, k, :lens[b, k]], ref[k][1]), (b, k, sizes[b])
+            else:
+                assert lens[b, k] == 0
+    dicts = consumer.rle_dicts(r)
+    assert all(d["size"] == [sizes[b][0], sizes[b][1]] for b in range(B) for d in dicts[b])
+
+
+@pytest.mark.parametrize("order", ["resize_then_threshold", "threshold_then_resize"])
+def test_outputs_smaller_than_the_mask(order):
+    """cv::resize with INTER_LINEAR shrinks with two taps and no anti-aliasing; the staging of the source columns
+    and the zero skipping must cope with scale factors above 1 (up to 13x here).  Exactly half in BOTH axes is
+    the one pair cv::resize hands to INTER_AREA: rejected by the library (and by the oracle)."""
+    import torch
+    from yolact_amd import _lib
+    rng = np.random.default_rng(18)
+    masks = _blobs(rng, 2, 4, 66, 80)
+    masks[1, 0] = rng.random((66, 80)).astype(np.float32)
+    for dst in ((33, 41), (34, 40), (65, 79), (5, 6), (20, 200), (130, 30), (66, 40), (33, 80)):
+        _check(masks, [4, 3], dst, order)
+    L = _lib.load()
+    m = torch.from_numpy(masks).cuda(); n = torch.tensor([4, 3], dtype=torch.int32).cuda()
+    counts = torch.zeros((2, 4, 64), dtype=torch.int32).cuda(); lens = torch.zeros((2, 4), dtype=torch.int32).cuda()
+    assert L.yp_masks_to_rle(0, 2, 4, 66, 80, m.data_ptr(), n.data_ptr(), 33, 40, 0.5, 0, None, counts.data_ptr(), lens.data_ptr(), 64, None) == -1
+    assert b"INTER_AREA" in L.yp_last_error()
+    with pytest.raises(ValueError):
+        co.resize_linear_f32(masks[0, 0], 33, 40)
 
 
 @pytest.mark.parametrize("use_crop", [True, False])

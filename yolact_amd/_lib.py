@@ -24,7 +24,7 @@ KERNEL_NAMES = ("score_filter", "nms", "mask_assemble")
 EXPORTS = ("yp_create", "yp_destroy", "yp_run", "yp_sync", "yp_last_survivors", "yp_profile_enable",
            "yp_profile_read", "yp_scratch_bytes", "yp_last_error", "yp_version", "yp_make_priors", "yp_run_static",
            "yp_masks_to_rle", "yp_rle_string", "yp_rle_strings", "yp_assemble_masks", "yp_assemble_masks_backward",
-           "yp_assemble_masks_backward_workspace", "yp_create_bounded", "yp_overflowed")
+           "yp_assemble_masks_backward_workspace", "yp_create_bounded", "yp_overflowed", "yp_masks_to_rle_sized")
 
 
 class YpConfig(ctypes.Structure):
@@ -86,6 +86,8 @@ def load():
     L.yp_masks_to_rle.restype = ctypes.c_int
     L.yp_masks_to_rle.argtypes = [ctypes.c_int32] * 5 + [vp, vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_float, ctypes.c_int32,
                                   vp, vp, vp, ctypes.c_int32, vp]
+    L.yp_masks_to_rle_sized.restype = ctypes.c_int
+    L.yp_masks_to_rle_sized.argtypes = [ctypes.c_int32] * 5 + [vp, vp, vp, ctypes.c_float, ctypes.c_int32, vp, vp, ctypes.c_int32, vp]
     L.yp_assemble_masks.restype = ctypes.c_int
     L.yp_assemble_masks.argtypes = [ctypes.c_int32] * 8 + [vp] * 6 + [vp]
     L.yp_assemble_masks_backward_workspace.restype = ctypes.c_int64

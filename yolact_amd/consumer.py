@@ -24,10 +24,13 @@ def masks_to_rle(det_masks: torch.Tensor, num_det: torch.Tensor, out_hw, thresho
     """Resize + binarise + run-length encode the first ``num_det[b]`` masks of every image.
 
     det_masks [B,max_dets,ph,pw] float32 and num_det [B] int32 are CUDA tensors (yp_run's outputs).
+    ``out_hw`` is one (height, width) for the whole batch, or a sequence of B such pairs - every image's own
+    original size, as ``coco_eval.py:112-137`` resizes them - which still is ONE call (no bitmaps then).
     Returns a dict: ``counts`` [B,max_dets,cap] int32 (bit pattern of uint32: uncompressed COCO
     counts, column-major, zeros first), ``len`` [B,max_dets] int32, ``bitmaps`` [B,max_dets,out_h,out_w]
-    uint8 or None.  If a detection has more runs than ``rle_cap`` the call is repeated once with room
-    for the longest list (that needs one synchronisation; pass a generous ``rle_cap`` to avoid it).
+    uint8 or None, ``size`` (h, w) or the list of them.  If a detection has more runs than ``rle_cap`` the call is
+    repeated once with room for the longest list (that needs one synchronisation; pass a generous ``rle_cap`` to
+    avoid it).
     """
     if not det_masks.is_cuda or det_masks.dtype != torch.float32 or det_masks.dim() != 4 or not det_masks.is_contiguous():
         raise ValueError("det_masks must be a contiguous float32 CUDA tensor [B,max_dets,ph,pw]")
@@ -35,21 +38,37 @@ def masks_to_rle(det_masks: torch.Tensor, num_det: torch.Tensor, out_hw, thresho
     dev = det_masks.device
     if num_det.device != dev or num_det.dtype != torch.int32 or tuple(num_det.shape) != (B,) or not num_det.is_contiguous():
         raise ValueError("num_det must be a contiguous int32 tensor [B] on the masks' device")
-    out_h, out_w = int(out_hw[0]), int(out_hw[1])
+    per_image = len(out_hw) > 0 and hasattr(out_hw[0], "__len__")
     L = _lib.load()
-    full = out_h * out_w + 1
-    cap = min(full, int(rle_cap) if rle_cap is not None else 8 * out_w + 64)
+    if per_image:
+        if len(out_hw) != B:
+            raise ValueError("out_hw must hold one (height, width) per image")
+        if bitmaps:
+            raise ValueError("bitmaps are not written with per-image sizes")
+        sizes = np.ascontiguousarray([[int(h), int(w)] for h, w in out_hw], dtype=np.int32).reshape(B, 2)
+        full = int((sizes[:, 0].astype(np.int64) * sizes[:, 1]).max()) + 1 if B else 1
+        widest = int(sizes[:, 1].max()) if B else 1
+        size_out = [(int(h), int(w)) for h, w in sizes]
+    else:
+        out_h, out_w = int(out_hw[0]), int(out_hw[1])
+        full, widest, size_out = out_h * out_w + 1, out_w, (out_h, out_w)
+    cap = min(full, int(rle_cap) if rle_cap is not None else 8 * widest + 64)
     bm = torch.empty((B, md, out_h, out_w), dtype=torch.uint8, device=dev) if bitmaps else None
     while True:
         counts = torch.empty((B, md, cap), dtype=torch.int32, device=dev)
         lens = torch.empty((B, md), dtype=torch.int32, device=dev)
         stream = torch.cuda.current_stream(dev).cuda_stream
-        _lib.check(L.yp_masks_to_rle(dev.index, B, md, ph, pw, det_masks.data_ptr(), num_det.data_ptr(), out_h, out_w,
-                                     float(threshold), ORDERS[order], bm.data_ptr() if bm is not None else None,
-                                     counts.data_ptr(), lens.data_ptr(), cap, ctypes.c_void_p(stream)))
+        if per_image:
+            _lib.check(L.yp_masks_to_rle_sized(dev.index, B, md, ph, pw, det_masks.data_ptr(), num_det.data_ptr(), sizes.ctypes.data,
+                                               float(threshold), ORDERS[order], counts.data_ptr(), lens.data_ptr(), cap,
+                                               ctypes.c_void_p(stream)))
+        else:
+            _lib.check(L.yp_masks_to_rle(dev.index, B, md, ph, pw, det_masks.data_ptr(), num_det.data_ptr(), out_h, out_w,
+                                         float(threshold), ORDERS[order], bm.data_ptr() if bm is not None else None,
+                                         counts.data_ptr(), lens.data_ptr(), cap, ctypes.c_void_p(stream)))
         need = int(lens.max().item()) if B * md > 0 else 0
         if need <= cap:
-            return {"counts": counts, "len": lens, "bitmaps": bm, "size": (out_h, out_w)}
+            return {"counts": counts, "len": lens, "bitmaps": bm, "size": size_out}
         cap = min(full, need)
 
 
@@ -99,18 +118,22 @@ def rle_dicts(rle: dict):
     flat = c2[used].cpu().numpy().view(np.uint32)                       # the lists back to back, in (b, n) order
     ln = lens.reshape(-1)
     starts = np.concatenate([[0], np.cumsum(ln[:-1], dtype=np.int64)]) if ln.size else np.zeros(0, np.int64)
-    h, w = rle["size"]
+    size = rle["size"]
+    sizes = size if isinstance(size, list) else [size] * B
     strs = rle_strings(flat, ln, starts)
-    return [[{"size": [h, w], "counts": strs[b * md + n]} for n in range(md) if lens[b, n] > 0] for b in range(B)]
+    return [[{"size": [sizes[b][0], sizes[b][1]], "counts": strs[b * md + n]} for n in range(md) if lens[b, n] > 0] for b in range(B)]
 
 
-def export_detections(result: dict, image_ids, orig_hw, score_thresh: float = 0.05, threshold: float = 0.5):
+def export_detections(result: dict, image_ids, orig_hw, score_thresh: float = 0.05, threshold: float = 0.5,
+                      return_boxes: bool = False):
     """The annotation list ``coco_eval.py:123-155`` builds from a Detect result (and
     ``utils/coco_tools.py:728-737`` for the evaluator): per image ``det_num = count_nonzero(scores >
-    0.05)`` rows, ``category_id = int(class)``, ``segmentation`` = the RLE of the mask resized to the
-    image's own (h, w) and thresholded, ``score = float(score)``.  ``_box_pixels`` carries the
-    ``[y1, x1, y2, x2]`` ints of L139-140 (the reference only draws them).  ``orig_hw[b]`` = (h, w) of
-    image b before it was resized for the network."""
+    0.05)`` rows, and per row EXACTLY the four keys of L150-155 - ``image_id``, ``category_id = int(class)``,
+    ``segmentation`` = the RLE of the mask resized to the image's own (h, w) and thresholded, ``score =
+    float(score)`` - so that ``json.dump`` of the list is what L158-159 writes.  ``orig_hw[b]`` = (h, w) of
+    image b before it was resized for the network.  All images go through ONE resize + RLE call, whatever
+    their sizes.  ``return_boxes=True`` returns ``(annotations, boxes)`` with the ``[y1, x1, y2, x2]`` ints
+    of L139-140 per annotation (the reference only draws them)."""
     masks, scores = result["detection_masks"], result["detection_scores"]
     B = masks.shape[0]
     det_num = (scores > score_thresh).sum(dim=1).to(torch.int32).contiguous()          # L123
@@ -118,27 +141,18 @@ def export_detections(result: dict, image_ids, orig_hw, score_thresh: float = 0.
     boxes = result["detection_boxes"].cpu().numpy()
     classes = result["detection_classes"].cpu().numpy()
     scores_h = scores.cpu().numpy()
-    sizes = {}
-    for b in range(B):
-        sizes.setdefault((int(orig_hw[b][0]), int(orig_hw[b][1])), []).append(b)
-    enc = [None] * B
-    for (h, w), members in sizes.items():            # one launch per distinct image size
-        idx = torch.as_tensor(members, device=masks.device)
-        sub = masks if len(members) == B else masks.index_select(0, idx).contiguous()
-        nd = det_num if len(members) == B else det_num.index_select(0, idx).contiguous()
-        dicts = rle_dicts(masks_to_rle(sub, nd, (h, w), threshold=threshold))
-        for j, b in enumerate(members):
-            enc[b] = dicts[j]
-    annotations = []
+    sizes = [(int(orig_hw[b][0]), int(orig_hw[b][1])) for b in range(B)]
+    enc = rle_dicts(masks_to_rle(masks, det_num, sizes, threshold=threshold))           # L131-137, every image at its own size
+    annotations, box_pixels = [], []
     for b, image_id in enumerate(image_ids):
-        _h, _w = int(orig_hw[b][0]), int(orig_hw[b][1])
+        _h, _w = sizes[b]
         det_boxes = boxes[b][:n_host[b]] * np.array([_h, _w, _h, _w])                   # L124-125
         for i in range(int(n_host[b])):
             _y1, _x1, _y2, _x2 = (int(v) for v in det_boxes[i].astype(int))             # L139-140
             annotations.append({"image_id": image_id, "category_id": int(classes[b][i]),      # L150-155
-                                "segmentation": enc[b][i], "score": float(scores_h[b][i]),
-                                "_box_pixels": [_y1, _x1, _y2, _x2]})
-    return annotations
+                                "segmentation": enc[b][i], "score": float(scores_h[b][i])})
+            box_pixels.append([_y1, _x1, _y2, _x2])
+    return (annotations, box_pixels) if return_boxes else annotations
 
 
 def assemble_loss_masks(proto: torch.Tensor, pos_coef: torch.Tensor, pos_prior_box: torch.Tensor, num_pos: torch.Tensor,

@@ -299,8 +299,10 @@ static __device__ __align__(256) unsigned char scratch[YP_STATIC_SCRATCH_BYTES];
 #define YP_STATIC_MAX_DEVICES 64
 static std::mutex g_static_mu;
 static unsigned char* g_static_ptr[YP_STATIC_MAX_DEVICES];    // per device; null = not resolved yet
-static yp_handle g_static_plan[YP_STATIC_MAX_DEVICES];        // host-side plan of the last config seen per device
-static bool g_static_plan_valid[YP_STATIC_MAX_DEVICES];
+#define YP_STATIC_PLANS 4                                     // configs remembered per device (round-robin replacement)
+static yp_handle g_static_plan[YP_STATIC_MAX_DEVICES][YP_STATIC_PLANS];   // host-side plans of the last configs seen per device
+static bool g_static_plan_valid[YP_STATIC_MAX_DEVICES][YP_STATIC_PLANS];
+static int g_static_plan_next[YP_STATIC_MAX_DEVICES];
 
 extern "C" int yp_run_static(const yp_config* cfg, int32_t batch, const float* pred_offset, const float* pred_cls,
                              const float* pred_mask_coef, const float* priors, const float* proto, float* det_boxes,
@@ -312,14 +314,22 @@ extern "C" int yp_run_static(const yp_config* cfg, int32_t batch, const float* p
     return fail(YP_ENODEV, "yp_run_static: device_id %d outside [0, %d)", cfg->device_id, YP_STATIC_MAX_DEVICES);
   std::lock_guard<std::mutex> lock(g_static_mu);   // one call at a time plans and launches (calls that OVERLAP on a GPU race on the scratch anyway)
   const int dev = cfg->device_id;
-  yp_handle* h = &g_static_plan[dev];
   yp_config want = *cfg;
   want.max_batch = 1;   // not part of this entry point's contract: any batch is cut to fit
-  if (!g_static_plan_valid[dev] || memcmp(&h->cfg, &want, sizeof(want)) != 0) {
-    g_static_plan_valid[dev] = false;
-    const int rc = plan_handle(want, h);   // validation + host-side plan; queries only, nothing allocated
+  // The plan of a (device, config) pair is made on the FIRST call with it - validation, attribute and occupancy
+  // queries, and once per device hipGetSymbolAddress: that call must be made eagerly, outside any graph capture -
+  // and remembered (a few configs per device, so callers that alternate configs do not re-plan every call).
+  yp_handle* h = nullptr;
+  for (int i = 0; i < YP_STATIC_PLANS; ++i)
+    if (g_static_plan_valid[dev][i] && memcmp(&g_static_plan[dev][i].cfg, &want, sizeof(want)) == 0) h = &g_static_plan[dev][i];
+  if (!h) {
+    const int slot = g_static_plan_next[dev];
+    g_static_plan_valid[dev][slot] = false;
+    const int rc = plan_handle(want, &g_static_plan[dev][slot]);   // validation + host-side plan; queries only, nothing allocated
     if (rc != YP_OK) return rc;
-    g_static_plan_valid[dev] = true;
+    g_static_plan_valid[dev][slot] = true;
+    g_static_plan_next[dev] = (slot + 1) % YP_STATIC_PLANS;
+    h = &g_static_plan[dev][slot];
   }
   const int rc = check_run_args(h, pred_offset, pred_cls, pred_mask_coef, priors, proto, det_boxes, det_classes, det_scores,
                                 det_masks, det_bitmaps, num_det);
@@ -439,27 +449,63 @@ extern "C" int64_t yp_make_priors(int32_t img_h, int32_t img_w, int32_t num_leve
   return n;
 }
 
-extern "C" int yp_masks_to_rle(int32_t device_id, int32_t batch, int32_t max_dets, int32_t mask_h, int32_t mask_w,
-                               const float* det_masks, const int32_t* num_det, int32_t out_h, int32_t out_w, float threshold,
-                               int32_t order, uint8_t* bitmaps, uint32_t* rle_counts, int32_t* rle_len, int32_t rle_cap,
-                               void* hip_stream) {
-  if (!det_masks || !num_det || !rle_counts || !rle_len) return fail(YP_EINVAL, "yp_masks_to_rle: null pointer");
-  if (batch < 0 || max_dets < 1 || mask_h < 1 || mask_w < 1 || out_h < 1 || out_w < 1 || rle_cap < 1)
-    return fail(YP_EINVAL, "yp_masks_to_rle: sizes must be positive");
-  if (order != YP_RESIZE_THEN_THRESHOLD && order != YP_THRESHOLD_THEN_RESIZE) return fail(YP_EINVAL, "yp_masks_to_rle: bad order");
+// cv::resize replaces INTER_LINEAR by INTER_AREA when both axes shrink by exactly 2 (imgproc resize.cpp:
+// `interpolation == INTER_LINEAR && is_area_fast && iscale_x == 2 && iscale_y == 2`), and its 2x2 float average
+// sums in an order that depends on the SIMD width of the build: not restated here, rejected instead.
+static int rle_check_size(const char* who, int mask_h, int mask_w, int out_h, int out_w, int max_out_h) {
+  if (out_h < 1 || out_w < 1) return fail(YP_EINVAL, "%s: output sizes must be positive", who);
+  if (out_h > max_out_h || out_w > 65535) return fail(YP_EINVAL, "%s: out_h <= %d and out_w <= 65535 are supported", who, max_out_h);
+  if (mask_h == 2 * out_h && mask_w == 2 * out_w)
+    return fail(YP_EINVAL, "%s: %dx%d -> %dx%d halves both axes exactly: cv::resize switches to INTER_AREA there, which this library "
+                           "does not restate", who, mask_h, mask_w, out_h, out_w);
+  return YP_OK;
+}
+
+static int masks_to_rle(const char* who, int32_t device_id, int32_t batch, int32_t max_dets, int32_t mask_h, int32_t mask_w,
+                        const float* det_masks, const int32_t* num_det, int32_t out_h, int32_t out_w, const int32_t* out_hw,
+                        float threshold, int32_t order, uint8_t* bitmaps, uint32_t* rle_counts, int32_t* rle_len, int32_t rle_cap,
+                        void* hip_stream) {
+  if (!det_masks || !num_det || !rle_counts || !rle_len) return fail(YP_EINVAL, "%s: null pointer", who);
+  if (batch < 0 || max_dets < 1 || mask_h < 1 || mask_w < 1 || rle_cap < 1) return fail(YP_EINVAL, "%s: sizes must be positive", who);
+  if (order != YP_RESIZE_THEN_THRESHOLD && order != YP_THRESHOLD_THEN_RESIZE) return fail(YP_EINVAL, "%s: bad order", who);
   int max_src_h, max_out_h;
   yp_rle_limits(&max_src_h, &max_out_h);
-  if (mask_h > max_src_h || out_h > max_out_h)
-    return fail(YP_EINVAL, "yp_masks_to_rle: mask_h <= %d and out_h <= %d are supported", max_src_h, max_out_h);
-  if (mask_w > 32767 || out_w > 65535 || max_dets > 65535 || batch > 65535) return fail(YP_EINVAL, "yp_masks_to_rle: size out of range");
+  if (mask_h > max_src_h) return fail(YP_EINVAL, "%s: mask_h <= %d is supported", who, max_src_h);
+  if (mask_w > 32767 || max_dets > 65535 || batch > 65535) return fail(YP_EINVAL, "%s: size out of range", who);
+  if (out_hw) {
+    if (bitmaps) return fail(YP_EINVAL, "%s: bitmaps are not written with per-image sizes", who);
+    for (int b = 0; b < batch; ++b) {
+      const int rc = rle_check_size(who, mask_h, mask_w, out_hw[2 * b], out_hw[2 * b + 1], max_out_h);
+      if (rc != YP_OK) return rc;
+    }
+  } else {
+    const int rc = rle_check_size(who, mask_h, mask_w, out_h, out_w, max_out_h);
+    if (rc != YP_OK) return rc;
+  }
   if (batch == 0) return YP_OK;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(YP_ENODEV, "no HIP device available");
   if (device_id < 0 || device_id >= ndev) return fail(YP_ENODEV, "device_id %d out of range (%d devices)", device_id, ndev);
   YP_ON_DEVICE(device_id);
-  YP_HIP(yp_launch_mask_rle(batch, max_dets, mask_h, mask_w, det_masks, num_det, out_h, out_w, threshold, order, bitmaps,
+  YP_HIP(yp_launch_mask_rle(batch, max_dets, mask_h, mask_w, det_masks, num_det, out_h, out_w, out_hw, threshold, order, bitmaps,
                             rle_counts, rle_len, rle_cap, (hipStream_t)hip_stream));
   return YP_OK;
+}
+
+extern "C" int yp_masks_to_rle(int32_t device_id, int32_t batch, int32_t max_dets, int32_t mask_h, int32_t mask_w,
+                               const float* det_masks, const int32_t* num_det, int32_t out_h, int32_t out_w, float threshold,
+                               int32_t order, uint8_t* bitmaps, uint32_t* rle_counts, int32_t* rle_len, int32_t rle_cap,
+                               void* hip_stream) {
+  return masks_to_rle("yp_masks_to_rle", device_id, batch, max_dets, mask_h, mask_w, det_masks, num_det, out_h, out_w, nullptr,
+                      threshold, order, bitmaps, rle_counts, rle_len, rle_cap, hip_stream);
+}
+
+extern "C" int yp_masks_to_rle_sized(int32_t device_id, int32_t batch, int32_t max_dets, int32_t mask_h, int32_t mask_w,
+                                     const float* det_masks, const int32_t* num_det, const int32_t* out_hw, float threshold,
+                                     int32_t order, uint32_t* rle_counts, int32_t* rle_len, int32_t rle_cap, void* hip_stream) {
+  if (!out_hw) return fail(YP_EINVAL, "yp_masks_to_rle_sized: null out_hw");
+  return masks_to_rle("yp_masks_to_rle_sized", device_id, batch, max_dets, mask_h, mask_w, det_masks, num_det, 0, 0, out_hw,
+                      threshold, order, nullptr, rle_counts, rle_len, rle_cap, hip_stream);
 }
 
 extern "C" int yp_assemble_masks(int32_t device_id, int32_t batch, int32_t rows, int32_t proto_h, int32_t proto_w, int32_t img_h,
@@ -498,7 +544,9 @@ extern "C" int yp_assemble_masks_backward(int32_t device_id, int32_t batch, int3
     return fail(YP_EINVAL, "yp_assemble_masks_backward: null pointer");
   if (batch < 0 || rows < 1 || rows > YP_SORT_MAX) return fail(YP_EINVAL, "yp_assemble_masks_backward: rows must be in [1, %d]", YP_SORT_MAX);
   if (proto_h < 1 || proto_w < 1 || img_h < 1 || img_w < 1) return fail(YP_EINVAL, "yp_assemble_masks_backward: bad proto/image size");
-  if (proto_w > 1024) return fail(YP_EINVAL, "yp_assemble_masks_backward: proto_w %d exceeds 1024 (a prototype row must fit in LDS)", proto_w);
+  // grad_coef keeps one prototype row in LDS: 160 bytes per pixel + 1 KiB, of the CU's 160 KiB.  Checked here,
+  // before anything is launched (above ~1017 the third launch failed after two had already run).
+  if (proto_w > 1000) return fail(YP_EINVAL, "yp_assemble_masks_backward: proto_w %d exceeds 1000 (a prototype row, 160 bytes per pixel, must fit in LDS)", proto_w);
   const long long P = (long long)proto_h * proto_w;
   if (P > (1ll << 26)) return fail(YP_EINVAL, "yp_assemble_masks_backward: %lld pixels per prototype exceed 2^26", P);
   if ((long long)batch * rows >= (1ll << 31) || (long long)batch * ((P + 255) / 256) >= (1ll << 31) || (long long)batch * proto_h >= (1ll << 31))

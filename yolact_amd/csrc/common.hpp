@@ -263,8 +263,8 @@ int yp_mask_prefill(const yp_handle* h, int batch);
 hipError_t yp_launch_mask_assemble(const yp_handle* h, int batch, const float* proto, const float* pred_mask_coef,
                                    const int32_t* num_det, float* det_masks, uint8_t* det_bitmaps, hipStream_t st);
 hipError_t yp_launch_mask_rle(int batch, int max_dets, int ph, int pw, const float* det_masks, const int32_t* num_det,
-                              int out_h, int out_w, float threshold, int order, uint8_t* bitmaps, uint32_t* counts,
-                              int32_t* rle_len, int cap, hipStream_t st);
+                              int out_h, int out_w, const int32_t* out_hw, float threshold, int order, uint8_t* bitmaps,
+                              uint32_t* counts, int32_t* rle_len, int cap, hipStream_t st);
 int yp_rle_limits(int* max_src_h, int* max_out_h);
 hipError_t yp_launch_loss_masks(int batch, int rows, int ph, int pw, int img_h, int img_w, int use_crop, const float* proto,
                                 const float* coef, const float* boxes, const int32_t* num_rows, float* crop_ws, float* out_masks,

@@ -164,7 +164,7 @@ __global__ __launch_bounds__(YP_WAVE, YP_SF_MIN_WAVES) void score_filter_kernel(
   // The whole per-load offset (lane16 + u KiB) travels as the VGPR offset (the compiler folds what fits
   // into the instruction's 12-bit immediate): the hardware range-checks VGPR offset + immediate only, an
   // SGPR offset is outside the check, and with it loads u >= 1 of a short last tile would read past the
-  // end of pred_cls (tests/test_gpu_parity.py::test_score_filter_reads_nothing_past_pred_cls).
+  // end of pred_cls (tests/test_abi.py::test_score_filter_buffer_loads_keep_their_offset_inside_the_range_check pins the emitted form).
   typedef unsigned int raw4 __attribute__((__vector_size__(4 * sizeof(unsigned int))));
   auto issue_loads = [&](int bb, int tt, bool on) {
     const int nbytes = on ? min(TA, p.A - tt * TA) * C * 4 : 0;
