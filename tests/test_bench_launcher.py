@@ -59,3 +59,27 @@ def test_two_ranks_on_the_one_gpu_box_shard_one_batch():
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
     assert d["config"]["batch_per_gpu"] == 4 and d["config"]["images_per_step"] == 8
     assert "sharded over 2" in d["config"]["workload"]
+
+
+def test_eight_ranks_rendezvous_and_cut_the_batches_of_configs_3_and_5():
+    """The 8-GPU shape of BASELINE configs 3 and 5 rehearsed on the CPU (gloo, no kernels): eight ranks, one batch of
+    64, eight contiguous chunks of 8 in rank order."""
+    for cfg in ("3", "5"):
+        p, lines = _run(["--gpus", "8", "--config", cfg, "--steps", "1", "--warmup", "0"],
+                        {"YP_BENCH_DRY": "1", "YP_BENCH_BACKEND": "gloo"}, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        d = json.loads(lines[0])
+        assert d["n_gpus"] == 8 and d["scaling"] == "strong"
+        assert [tuple(c) for c in d["config"]["chunks"]] == [(8 * r, 8 * r + 8) for r in range(8)]
+
+
+def test_launcher_stops_the_other_ranks_when_one_dies():
+    """A rank that fails before the rendezvous leaves the others waiting for it: the launcher must notice, stop
+    them and exit non-zero instead of hanging."""
+    import time
+    t0 = time.monotonic()
+    p, lines = _run(["--gpus", "3", "--steps", "1", "--warmup", "0"],
+                    {"YP_BENCH_DRY": "1", "YP_BENCH_BACKEND": "gloo", "YP_BENCH_DIE_RANK": "1"}, timeout=240)
+    assert p.returncode != 0 and not lines
+    assert "rank 1 exited with status 3" in p.stderr
+    assert time.monotonic() - t0 < 120

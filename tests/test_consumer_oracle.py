@@ -68,8 +68,14 @@ def test_resize_known_answers():
     # R = [0, 512, 1536, 2048] -> R>>4 = [0, 32, 96, 128]; b0 = 2048: (2048*v)>>16 = [0, 1, 3, 4]; (+2)>>2 = [0, 0, 1, 1]
     r8 = co.resize_linear_u8(np.array([[0, 1]], np.uint8), 1, 4)
     assert r8.tolist() == [[0, 0, 1, 1]]
-    # downscale path is defined too (not used by the reference's callers, which only enlarge)
-    assert co.resize_linear_f32(np.ones((8, 8), np.float32), 4, 4).shape == (4, 4)
+    # shrinking is two-tap INTER_LINEAR as well: 1x4 -> 1x3, scale 4/3: fx = (dx+.5)*4/3-.5 = 1/6, 1.5, 17/6 -> taps
+    # (0,1) w 1/6, (1,2) w .5, (2,3) w 5/6
+    r = co.resize_linear_f32(np.array([[0.0, 3.0, 6.0, 9.0]], np.float32), 1, 3)
+    assert np.allclose(r, [[0.5, 4.5, 8.5]], atol=1e-6)
+    # ... except exactly half in both axes, which cv::resize hands to INTER_AREA: not restated, refused
+    with pytest.raises(ValueError):
+        co.resize_linear_f32(np.ones((8, 8), np.float32), 4, 4)
+    assert co.resize_linear_f32(np.ones((8, 8), np.float32), 4, 8).shape == (4, 8)        # one axis only: still linear
 
 
 def test_threshold_orders_differ_only_near_edges():

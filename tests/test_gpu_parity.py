@@ -444,7 +444,12 @@ def test_sharded_detect_matches_unsharded(torch_cuda):
     net, shp = synth.make_toy(31, batch=5)
     kw = dict(strict_reference=False, nms_mode="per_class", top_k=50, max_dets=20)
     one = to_numpy(Detect(5, 100, 100, 0.05, 0.5, **kw)(net, shp))
-    two = ShardedDetect(5, 100, 100, 0.05, 0.5, devices=[0, 0], **kw)(net, shp)
+    sd = ShardedDetect(5, 100, 100, 0.05, 0.5, devices=[0, 0], **kw)
+    two = sd(net, shp)
+    assert all(v.is_pinned() and v.shape[0] == 5 for v in two.values())          # whole-batch pinned buffers, no concatenation
+    assert [t["images"] for t in sd.last_timing] == [3, 2] and all(t["compute_ms"] > 0 and t["gather_ms"] >= 0 for t in sd.last_timing)
+    again = sd(net, shp)
+    assert all(again[k].data_ptr() == two[k].data_ptr() for k in two)           # the buffers are reused call after call
     two = {k: (v.numpy() if hasattr(v, "numpy") else v) for k, v in two.items()}
     for k in ("detection_boxes", "detection_classes", "detection_scores", "detection_masks", "num_detections",
               "detection_anchor_indices"):

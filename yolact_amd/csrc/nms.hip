@@ -1327,7 +1327,7 @@ static NmsArgs make_args(const yp_handle* h, int batch, const float* pred_offset
 }
 
 #ifndef YP_FILL_WGS_PER_CU
-#define YP_FILL_WGS_PER_CU 3   // fill workgroups of an NMS launch per compute unit (each walks its share of the chunks)
+#define YP_FILL_WGS_PER_CU 6   // fill workgroups of an NMS launch per compute unit (each walks its share of the chunks)
 #endif
 
 // NMS (both modes; in per-class mode including the final selection) plus, when fill_masks is given,
@@ -1339,7 +1339,7 @@ hipError_t yp_launch_nms(const yp_handle* h, int batch, const float* pred_offset
   a.arrive = h->s.arrive;
   a.fill_masks = fill_masks; a.fill_bitmaps = fill_masks ? fill_bitmaps : nullptr;
   a.fill_P = (long long)h->cfg.proto_h * h->cfg.proto_w; a.fill_rows = fill_rows; a.batch = batch;
-  const long long max_wgs = (long long)h->num_cus * YP_FILL_WGS_PER_CU;
+  const long long max_wgs = YP_FILL_WGS_PER_CU > 0 ? (long long)h->num_cus * YP_FILL_WGS_PER_CU : 0x7fffffffll - (long long)batch * YP_NLISTS;   // (0: a workgroup per chunk)
   if (h->cfg.nms_mode == YP_NMS_CROSS_CLASS) {
     constexpr int T = YP_CC_THREADS;
     a.nms_blocks = batch;

@@ -65,9 +65,15 @@ class ShardedDetect:
 
     One worker thread per device: a shard's host-to-device copies, its launches and its copy back all
     happen on that device's thread (torch releases the GIL inside the copies, HIP's current device is
-    per thread), so the devices really run side by side; the caller's thread only concatenates."""
+    per thread), so the devices really run side by side.  The results land in PINNED host buffers that hold
+    the whole batch - every shard copies into its own slice with non-blocking copies and ONE stream
+    synchronisation - so the "concatenation in image order" is the buffer itself.  The returned tensors are
+    views of those buffers: they are overwritten by the next call with the same batch shape (clone what must
+    outlive it).  ``last_timing`` holds, per shard, the device time of the post-processing and of the gather
+    (HIP events on the shard's stream)."""
 
     def __init__(self, *detect_args, devices=None, **detect_kwargs):
+        import threading
         import torch
         from concurrent.futures import ThreadPoolExecutor
         from .detect import Detect
@@ -76,6 +82,19 @@ class ShardedDetect:
         self.devices = list(devices) if devices is not None else list(range(torch.cuda.device_count()))
         self.detects = [Detect(*detect_args, device=f"cuda:{d}", **detect_kwargs) for d in self.devices]
         self._pool = ThreadPoolExecutor(max_workers=max(1, len(self.devices)), thread_name_prefix="yp-shard")
+        self._lock = threading.Lock()
+        self._host = {}           # (batch, key, shape, dtype) -> pinned tensor [batch, ...]
+        self.last_timing = []
+
+    def _host_buffer(self, batch, key, t):
+        import torch
+        sig = (batch, key, tuple(t.shape[1:]), t.dtype)
+        with self._lock:
+            buf = self._host.get(sig)
+            if buf is None:
+                buf = torch.empty((batch,) + tuple(t.shape[1:]), dtype=t.dtype, pin_memory=True)
+                self._host[sig] = buf
+            return buf
 
     def __call__(self, net_outs, img_shape, trad_nms=False, use_cropped_mask=True):
         import torch
@@ -87,8 +106,25 @@ class ShardedDetect:
             if hi <= lo:
                 return None
             with torch.cuda.device(self.detects[r].device):
+                st = torch.cuda.current_stream()
+                e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+                e0.record(st)
                 res = self.detects[r](slice_net_outs(net_outs, lo, hi), img_shape, trad_nms, use_cropped_mask)
-                return {k: v.cpu() for k, v in res.items()}
+                e1.record(st)
+                views = {}
+                for k, v in res.items():
+                    buf = self._host_buffer(B, k, v)
+                    buf[lo:hi].copy_(v, non_blocking=True)
+                    views[k] = buf
+                e2.record(st)
+                st.synchronize()                                       # the shard's one synchronisation
+                return views, {"device": self.devices[r], "images": hi - lo, "compute_ms": e0.elapsed_time(e1),
+                               "gather_ms": e1.elapsed_time(e2)}
 
         futures = [self._pool.submit(work, r) for r in range(G)]      # every shard is in flight before any is awaited
-        return concat_results([f.result() for f in futures])             # image order
+        done = [f.result() for f in futures]
+        done = [d for d in done if d is not None]
+        if not done:
+            raise ValueError("no results")
+        self.last_timing = [d[1] for d in done]
+        return dict(done[0][0])                                         # whole-batch buffers, image order
