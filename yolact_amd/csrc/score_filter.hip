@@ -187,57 +187,73 @@ __global__ __launch_bounds__(YP_WAVE, YP_SF_MIN_WAVES) void score_filter_kernel(
     // in the same instruction.  (One instruction per list, issued back to back, cost 8 us per launch at config 2
     // and 30 at config 4: a wave's returning agent-scope atomics are served one after the other, ~0.5 us each;
     // tools/atomic_probe.hip.)
-    auto flush = [&]() {   // wave-uniform
-      __builtin_amdgcn_wave_barrier();
-      for (int l0 = 0; l0 < nbuf; l0 += YP_WAVE) {
-        const bool has = l0 + lane < nbuf;
-        const u64 key = s_key[min(l0 + lane, nbuf - 1)];
-        const int anchor = min(yp_seg_key_anchor(key), p.A - 1);
-        const float4 pr = p.priors[anchor], of = p.off[(size_t)b * p.A + anchor];
-        int lst;
+    // A batch of up to 64 parked keys on its way out, in two halves so that the memory latencies of the first -
+    // the slot atomics and the gather of prior and offsets - can pass while the wave does something else.
+    struct Batch { bool has; u64 key; float4 pr, of; int lst, base, leader, rank; };
+    auto batch_issue = [&](int l0) -> Batch {   // keys s_key[l0 .. min(l0 + 64, nbuf)); no wait inside
+      Batch q;
+      q.has = l0 + lane < nbuf;
+      q.key = s_key[min(l0 + lane, nbuf - 1)];
+      const int anchor = min(yp_seg_key_anchor(q.key), p.A - 1);
+      q.pr = p.priors[anchor];
+      q.of = p.off[(size_t)b * p.A + anchor];
 #ifdef YP_EXP_ONE_ATOMIC   // experiment build (timing only, wrong results): what do the per-list atomics cost?
-        if (true) {
+      if (true) {
 #else
-        if (MODE == YP_NMS_CROSS_CLASS) {
+      if (MODE == YP_NMS_CROSS_CLASS) {
 #endif
-          lst = part & (YP_NLISTS - 1);
+        q.lst = part & (YP_NLISTS - 1);
+      } else {
+        // (c - 1) % ngroups without the integer division: (x + 0.5) / n is at least 0.5 / n away from an
+        // integer for 0 <= x < 256, n <= 16 - far more than the float error - so the truncation is x / n
+        const int c1 = yp_seg_key_class(q.key) - 1;
+        q.lst = c1 - (int)(((float)c1 + 0.5f) * ginv) * p.ngroups;
+      }
+      int32_t* const cnt = p.lcount + ((size_t)b * YP_NLISTS) * YP_CNT_STRIDE;
+      u64 rest = __ballot(q.has);
+      int share = 0;
+      q.base = 0; q.leader = 0; q.rank = 0;
+      while (rest != 0ull) {   // (one trip in cross-class mode; no memory operation inside)
+        const int l1 = __builtin_ctzll(rest);
+        const int g1 = __builtin_amdgcn_readlane(q.lst, l1);
+        const u64 mm = __ballot(q.lst == g1) & rest;
+        if (q.has && q.lst == g1) { q.leader = l1; q.rank = __popcll(mm & lt_mask); }
+        if (lane == l1) share = __popcll(mm);
+        rest &= ~mm;
+      }
+      if (share != 0) q.base = __hip_atomic_fetch_add(cnt + q.lst * YP_CNT_STRIDE, share, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return q;
+    };
+    auto batch_commit = [&](const Batch& q) {
+      const float4 box = yp_decode(q.pr, q.of);                                           // detection.py:79
+      const int slot = __shfl(q.base, q.leader) + q.rank;
+      if (q.has) {
+        if (slot < p.lcap) {
+          const size_t o = ((size_t)b * YP_NLISTS + q.lst) * p.lcap + slot;
+          p.lkeys[o] = q.key;
+          p.lbox[o] = box;
         } else {
-          // (c - 1) % ngroups without the integer division: (x + 0.5) / n is at least 0.5 / n away from an
-          // integer for 0 <= x < 256, n <= 16 - far more than the float error - so the truncation is x / n
-          const int c1 = yp_seg_key_class(key) - 1;
-          lst = c1 - (int)(((float)c1 + 0.5f) * ginv) * p.ngroups;
-        }
-        int32_t* const cnt = p.lcount + ((size_t)b * YP_NLISTS) * YP_CNT_STRIDE;
-        u64 rest = __ballot(has);
-        int base = 0, leader = 0, rank = 0, share = 0;
-        while (rest != 0ull) {   // (one trip in cross-class mode; no memory operation inside)
-          const int l1 = __builtin_ctzll(rest);
-          const int g1 = __builtin_amdgcn_readlane(lst, l1);
-          const u64 mm = __ballot(lst == g1) & rest;
-          if (has && lst == g1) { leader = l1; rank = __popcll(mm & lt_mask); }
-          if (lane == l1) share = __popcll(mm);
-          rest &= ~mm;
-        }
-        if (share != 0) base = __hip_atomic_fetch_add(cnt + lst * YP_CNT_STRIDE, share, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const float4 box = yp_decode(pr, of);                                             // detection.py:79
-        const int slot = __shfl(base, leader) + rank;
-        if (has) {
-          if (slot < p.lcap) {
-            const size_t o = ((size_t)b * YP_NLISTS + lst) * p.lcap + slot;
-            p.lkeys[o] = key;
-            p.lbox[o] = box;
-          } else {
-            // the list is full (only a batch far from anything a detector emits gets here): the key alone goes
-            // to the image's overflow list, which every class group then also reads
-            const int os = p.ocap > 0 ? __hip_atomic_fetch_add(p.ocount + (size_t)b * YP_CNT_STRIDE, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                                      : 0x7fffffff;
-            if (os < p.ocap) p.okeys[(size_t)b * p.ocap + os] = key;
-            else *p.overflow = 1;   // (bounded lists only: the key is dropped)
-          }
+          // the list is full (only a batch far from anything a detector emits gets here): the key alone goes
+          // to the image's overflow list, which every class group then also reads
+          const int os = p.ocap > 0 ? __hip_atomic_fetch_add(p.ocount + (size_t)b * YP_CNT_STRIDE, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                    : 0x7fffffff;
+          if (os < p.ocap) p.okeys[(size_t)b * p.ocap + os] = q.key;
+          else *p.overflow = 1;   // (bounded lists only: the key is dropped)
         }
       }
+    };
+    auto flush = [&]() {   // wave-uniform: everything parked leaves now, and the wave waits for it
+      __builtin_amdgcn_wave_barrier();
+#ifdef YP_EXP_NO_FLUSH   // experiment build (timing only, no candidates leave): what does the flush cost?
+      nbuf = 0;
+#endif
+      for (int l0 = 0; l0 < nbuf; l0 += YP_WAVE) batch_commit(batch_issue(l0));
       nbuf = 0;
     };
+    // (Tried: the keys of all tiles but the last issued - atomics, gather - when the last tile's processing starts and
+    //  committed when it ends, so that only the last tile's handful waits at the item's end: 55.3 us per launch at
+    //  config 2 against 51.4 with the one flush at the end; flushing synchronously before the last tile: 52.7.  For
+    //  reference: 44.7 with no flush at all, 48.4 with one atomic per flush instead of one per list.)
     if (FAST) issue_loads(b, t_begin, t_begin < t_end);
 
     for (int tix = t_begin; tix < t_end; ++tix) {
@@ -252,6 +268,13 @@ __global__ __launch_bounds__(YP_WAVE, YP_SF_MIN_WAVES) void score_filter_kernel(
 #pragma unroll
         for (int u = 0; u < NLD; ++u) t4[u * YP_WAVE + lane] = stg[u];
         issue_loads(b, min(tix + 1, t_end - 1), tix + 1 < t_end);
+      } else {
+            early = batch_issue(0);
+            early_pending = true;
+            nbuf = 0;                         // the keys are in registers: the last tile parks its own from slot 0
+          }
+        }
+#endif
       } else {
         const int nelem = na * C;
         const float* __restrict__ src = p.cls + ((size_t)b * p.A + a0) * C;
