@@ -269,13 +269,6 @@ __global__ __launch_bounds__(YP_WAVE, YP_SF_MIN_WAVES) void score_filter_kernel(
         for (int u = 0; u < NLD; ++u) t4[u * YP_WAVE + lane] = stg[u];
         issue_loads(b, min(tix + 1, t_end - 1), tix + 1 < t_end);
       } else {
-            early = batch_issue(0);
-            early_pending = true;
-            nbuf = 0;                         // the keys are in registers: the last tile parks its own from slot 0
-          }
-        }
-#endif
-      } else {
         const int nelem = na * C;
         const float* __restrict__ src = p.cls + ((size_t)b * p.A + a0) * C;
         for (int e = lane; e < nelem; e += YP_WAVE) {
