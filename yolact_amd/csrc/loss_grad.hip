@@ -161,6 +161,91 @@ __global__ __launch_bounds__(YP_GC_THREADS) void loss_grad_coef_rows_kernel(cons
   }
 }
 
+#ifdef YP_EXP_GC_MFMA
+// EXPERIMENT BUILD (-DYP_EXP_GC_MFMA, never the shipped library): step 1 on the matrix cores.  The one GEMM-shaped
+// piece of this path is [detections x pixels of a row] x [pixels x 32 coefficients]; here a wave takes 32 of the
+// row's detections at a time, lays their dz out in LDS in chunks of 64 pixels (zeros outside each detection's
+// x-range) and accumulates D[32 det][32 k] with v_mfma_f32_32x32x2_f32 (K = 2 pixels per instruction).  The sum over
+// x is then in the matrix core's order, not the fma chain's: results agree with the chain to rounding, not to the bit
+// (tools/gc_mfma_check.py reports the distance).  MEASURED (config 2's shape, 3200 rows, boxes of 10-60 % of the
+// image side, rocprofv3 --kernel-trace, profiles/r03/gc_mfma_experiment.md): 177.5 us against the chain kernel's
+// 72.5 us (first version, one load round trip per detection: 276 us).  SQ_VALU_MFMA_BUSY_CYCLES = 30.8 M = 481 k
+// instructions x 64 cycles, 6.8 % of the launch's SIMD cycles: the matrix cores are not the limit, the dense A
+// operand is - a row's 32 detections cover ~36 % of the chunk columns each, so two thirds of the LDS fill and of the
+// products are zeros, while the chain visits only in-box pixels.  The results came out bit-identical to the chain's
+// (the f32 MFMA accumulated its K steps as fused multiply-adds in k order on this hardware; observed, not specified).
+// The chain kernel stays the shipped one.
+typedef float yp_f32x16 __attribute__((ext_vector_type(16)));
+#define YP_GM_CHUNK 64
+#define YP_GM_STRIDE (YP_GM_CHUNK + 1)          // odd: the 32 detections of an A operand read hit 32 banks
+__global__ __launch_bounds__(YP_GC_THREADS) void loss_grad_coef_rows_mfma_kernel(const LossGradArgs a, int pwc) {
+  extern __shared__ __align__(16) float lg_lds[];
+  float* const prow = lg_lds;                                            // [pwc][32], rows >= pw are zeros
+  float* const dzs = prow + (size_t)pwc * YP_MASK_DIM;                   // [waves][32][YP_GM_STRIDE]
+  int* const rel = reinterpret_cast<int*>(dzs + (YP_GC_THREADS / 64) * 32 * YP_GM_STRIDE);   // [256] detection
+  int* const relx = rel + 256;                                           // [256] x0 | x1 << 16
+  __shared__ int nrel;
+  const int b = (int)blockIdx.x / a.ph, y = (int)blockIdx.x - b * a.ph;
+  const int t = (int)threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int N = min(a.num_rows[b], a.rows);
+  if (t == 0) nrel = 0;
+  {
+    const float4* src = reinterpret_cast<const float4*>(a.proto + ((size_t)b * a.P + (size_t)y * a.pw) * YP_MASK_DIM);
+    float4* dst = reinterpret_cast<float4*>(prow);
+    const int live = a.pw * (YP_MASK_DIM / 4), all = pwc * (YP_MASK_DIM / 4);
+    for (int i = t; i < all; i += YP_GC_THREADS) dst[i] = i < live ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  __syncthreads();
+  for (int n = t; n < N; n += YP_GC_THREADS) {
+    int x0, x1, y0, y1;
+    box_range(a.crop[(size_t)b * a.rows + n], a.pw, a.ph, x0, x1, y0, y1);
+    if (y >= y0 && y < y1 && x0 < x1) { const int s = atomicAdd(&nrel, 1); rel[s] = n; relx[s] = x0 | (x1 << 16); }
+  }
+  __syncthreads();
+  const int nr = nrel;
+  float* const dzw = dzs + wave * 32 * YP_GM_STRIDE;
+  const int li = lane & 31, lh = lane >> 5;
+  for (int g0 = wave * 32; g0 < nr; g0 += (YP_GC_THREADS / 64) * 32) {   // (uniform per wave)
+    const int cnt = min(32, nr - g0);
+    int xa = a.pw, xb = 0;
+    for (int i = 0; i < cnt; ++i) { const int xx = relx[g0 + i]; xa = min(xa, xx & 0xffff); xb = max(xb, xx >> 16); }
+    yp_f32x16 acc;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) acc[v] = 0.0f;
+    for (int c0 = xa & ~(YP_GM_CHUNK - 1); c0 < xb; c0 += YP_GM_CHUNK) {
+      const int x = c0 + lane;
+      for (int i0 = 0; i0 < 32; i0 += 8) {       // eight detections' loads in flight: clamped addresses, no branches
+        float gv[8], mv[8];
+        bool ok[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int s = g0 + min(i0 + u, cnt - 1);
+          const int xx = relx[s], x0 = xx & 0xffff, x1 = xx >> 16;
+          const size_t o = ((size_t)b * a.rows + rel[s]) * a.P + (size_t)y * a.pw + min(max(x, x0), x1 - 1);
+          gv[u] = a.grad[o]; mv[u] = a.masks[o];
+          ok[u] = (i0 + u < cnt) && x >= x0 && x < x1;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) dzw[(i0 + u) * YP_GM_STRIDE + lane] = ok[u] ? dz_of(gv[u], mv[u]) : 0.0f;
+      }
+      __builtin_amdgcn_wave_barrier();
+      const int ce = min(YP_GM_CHUNK, xb - c0);
+      for (int j = 0; j < ce; j += 2) {
+        const float av = dzw[li * YP_GM_STRIDE + j + lh];
+        const float bv = prow[(size_t)(c0 + j + lh) * YP_MASK_DIM + li];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+      const int i = 8 * (v >> 2) + lh * 4 + (v & 3);
+      if (i < cnt) a.part[(((size_t)b * a.rows + rel[g0 + i]) * a.ph + y) * YP_MASK_DIM + li] = acc[v];
+    }
+  }
+}
+#endif
+
 // grad_coef, step 2: the rows' values of a detection added up in ascending y, from +0 (a half-wave per detection).
 __global__ __launch_bounds__(YP_GC_THREADS) void loss_grad_coef_sum_kernel(const LossGradArgs a, int total) {
   const int t = (int)threadIdx.x, k = t & (YP_MASK_DIM - 1), h = t / YP_MASK_DIM;
@@ -208,7 +293,18 @@ hipError_t yp_launch_loss_grads(int batch, int rows, int ph, int pw, int img_h, 
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&loss_grad_coef_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
   }
+#ifdef YP_EXP_GC_MFMA
+  {
+    const int pwc = (pw + YP_GM_CHUNK - 1) / YP_GM_CHUNK * YP_GM_CHUNK;     // the chunks' last pixels read zero rows
+    const size_t ml = ((size_t)pwc * YP_MASK_DIM + (size_t)(YP_GC_THREADS / 64) * 32 * YP_GM_STRIDE) * sizeof(float) + 512 * sizeof(int);
+    if (ml > 64 * 1024) return hipErrorInvalidValue;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&loss_grad_coef_rows_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ml);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(loss_grad_coef_rows_mfma_kernel, dim3(batch * ph), dim3(YP_GC_THREADS), ml, st, a, pwc);
+  }
+#else
   hipLaunchKernelGGL(loss_grad_coef_rows_kernel, dim3(batch * ph), dim3(YP_GC_THREADS), lds, st, a, pwp);
+#endif
   const int total = batch * rows;
   hipLaunchKernelGGL(loss_grad_coef_sum_kernel, dim3((total + YP_GC_HALVES - 1) / YP_GC_HALVES), dim3(YP_GC_THREADS), 0, st, a, total);
   return hipGetLastError();
