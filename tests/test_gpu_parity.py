@@ -115,6 +115,37 @@ def test_config1_random_init_has_no_survivors(torch_cuda):
     check_vs_c_oracle(torch_cuda, net, shp, mode="cc", top_k=15, max_dets=15, label="cfg1-planted")
 
 
+@pytest.mark.parametrize("nb", [1, 2, 4])
+@pytest.mark.parametrize("mode,top_k,max_dets", [("cc", 15, 15), ("per_class", 200, 100)])
+def test_small_batches_in_the_shape_of_the_reference_call(torch_cuda, nb, mode, top_k, max_dets):
+    """infer.py:5-11 calls the model on one image: BASELINE config 1 at B = 1, 2, 4 in both modes.  In cross-class mode
+    these batches take the selection from registers (every candidate list fits the first batch of loads)."""
+    from yolact_amd import synth
+    cfg = synth.CONFIGS[1]
+    net, shp = synth.make_batch(cfg, batch=nb, mode="planted")
+    got, ref = check_vs_c_oracle(torch_cuda, net, shp, mode=mode, top_k=top_k, max_dets=max_dets, conf=cfg.conf_thresh,
+                                 label=f"cfg1-B{nb}-{mode}")
+    assert (ref["num_detections"] > 0).all()
+
+
+@pytest.mark.parametrize("top_k,max_dets", [(15, 15), (200, 100)])
+def test_cross_class_selection_when_the_scores_share_one_bin(torch_cuda, top_k, max_dets):
+    """600 anchors with identical logits (equal scores; tf.math.top_k takes the lower index first) beside a few
+    stronger ones: the fixed score bins of the selection from registers cannot isolate <= 256 keys around the k-th,
+    so the general selection has to take over - with the same result."""
+    from yolact_amd import synth
+    cfg = synth.CONFIGS[2]
+    net, shp = synth.make_batch(cfg, batch=2)
+    cls = net["pred_cls"]
+    cls[:] = 0.0
+    cls[..., 0] = 8.0
+    same = np.arange(7, cls.shape[1], 32)[:600]
+    cls[:, same, 5] = 9.0
+    cls[1, same[::100], 9] = 11.0          # image 1: six candidates above the plateau
+    got, ref = check_vs_c_oracle(torch_cuda, net, shp, mode="cc", top_k=top_k, max_dets=max_dets, label="plateau")
+    assert (ref["num_survivors"] >= 600).all()
+
+
 @pytest.mark.parametrize("mode", ["per_class", "cc"])
 def test_config4_nms_stress_bit_exact(torch_cuda, mode):
     """conf 0.01, every anchor planted: saturated top-200 in all 80 classes; in cc mode the image holds

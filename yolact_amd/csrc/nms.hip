@@ -73,6 +73,9 @@ struct NmsArgs {
 
   float nms_thresh, img_h, img_w, proto_h, proto_w;
   int use_crop;
+  // cross-class selection from registers: bin = min((score bits - sel_base) >> sel_shift, YP_RADIX_BINS - 1)
+  uint32_t sel_base;          // float bits of the confidence threshold (every candidate's score is above it)
+  int sel_shift;              // smallest shift that maps scores up to 1.0 into the bins
 #ifdef YP_STAMPS
   unsigned long long* dbg;   // diagnostic build: [kernel 0..2][block][16] cycle stamps of thread 0
 #endif
@@ -272,13 +275,14 @@ __device__ __forceinline__ int block_sum(int v, int* wtot) {   // wtot: >= THREA
   return s;
 }
 
+template <int THREADS> __device__ __forceinline__ void hist_locate(int need, SelectShared& sh);
 // One histogram pass over the keys with (key & mask) == prefix, digit = (key >> shift) & dmask.
 // Finds the bin that holds the need-th largest of them: sh.sel = bin, sh.need = how many are still
 // to be taken inside that bin, sh.cnt = keys in that bin.  Four barriers.
 template <int THREADS, class Src>
 __device__ __forceinline__ void hist_pass(const Src& src, u64 mask, u64 prefix, int shift, u64 dmask, int need, SelectShared& sh) {
   constexpr int BPT = YP_RADIX_BINS / THREADS;   // bins per thread
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int t = threadIdx.x;
 #pragma unroll
   for (int i = 0; i < BPT; ++i) sh.hist[t * BPT + i] = 0;
   __syncthreads();
@@ -286,6 +290,14 @@ __device__ __forceinline__ void hist_pass(const Src& src, u64 mask, u64 prefix, 
     if ((key & mask) == prefix) atomicAdd(&sh.hist[(int)((key >> shift) & dmask)], 1);
   });
   __syncthreads();
+  hist_locate<THREADS>(need, sh);
+}
+// The bin of the filled histogram sh.hist[] that holds the need-th largest key (bins are monotone in the key):
+// sh.sel, sh.need, sh.cnt as above.  Two barriers.
+template <int THREADS>
+__device__ __forceinline__ void hist_locate(int need, SelectShared& sh) {
+  constexpr int BPT = YP_RADIX_BINS / THREADS;   // bins per thread
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   int loc[BPT];
   int tsum = 0;
 #pragma unroll
@@ -756,6 +768,11 @@ __global__ __launch_bounds__(THREADS) void cc_nms_kernel(const NmsArgs p) {
     src.pre[u] = lk[o];
     preb[u] = lb[o];
   }
+  // (while the loads are under way) what the selection from registers expects to be zero
+#pragma unroll
+  for (int i = 0; i < YP_RADIX_BINS / THREADS; ++i) s_hist[t * (YP_RADIX_BINS / THREADS) + i] = 0;
+  if (t < YP_SORT_MAX) { sh.rank[t] = 0; ssup[t] = 0; }
+  if (t == 0) sh.fill = 0;
   int part = 0;
   for (int i = t; i < p.parts; i += THREADS) part += p.seg_surv[(size_t)b * p.parts + i];
   if (q == 0) {
@@ -772,14 +789,70 @@ __global__ __launch_bounds__(THREADS) void cc_nms_kernel(const NmsArgs p) {
     return;
   }
   STAMP(1);
-#ifdef YP_STAMPS
-  const int k = select_topk_sorted<THREADS>(src, n, p.top_k, sh, stage, YP_STAGE_CAP, dbg_);
-#else
-  const int k = select_topk_sorted<THREADS>(src, n, p.top_k, sh, stage, YP_STAGE_CAP);       // detection.py:186
-#endif
+  const int k = min(p.top_k, n);
+  // ---- selection from registers (the usual case: no list is longer than the first batch) ----------------------
+  // Small batches are latency: the general selection below costs ten barriers (min/max pass, histogram, take,
+  // rank sort, box placement).  Here the bins are fixed in advance - the score bits above the confidence
+  // threshold, cut to 11 bits: monotone in the key, which is all the selection needs - so the keys go from the
+  // registers straight into the histogram, the keys of the k-th bin and above are taken TOGETHER WITH their boxes,
+  // and the rank sort drops both at their place: six barriers.  The result is the same k keys in the same order
+  // (unique keys); if the fixed bins do not isolate <= 256 keys the general path runs instead.
+  bool in_regs = true;
+#pragma unroll
+  for (int i = 0; i < YP_NLISTS; ++i) in_regs = in_regs && s_cnt[i] <= YP_CC_PRE * YP_WAVE;
+  int m = -1;
+  if (in_regs) {                                                // (workgroup-uniform)
+    float4* const tbox = reinterpret_cast<float4*>(stage);     // idle here: only the general path stages keys
+    const int nl = s_cnt[l];
+    int bin[YP_CC_PRE];
+#pragma unroll
+    for (int u = 0; u < YP_CC_PRE; ++u) {
+      const uint32_t sb = (uint32_t)(src.pre[u] >> 32);
+      bin[u] = q + u * YP_WAVE < nl ? (int)min((sb > p.sel_base ? sb - p.sel_base : 0u) >> p.sel_shift, (uint32_t)(YP_RADIX_BINS - 1)) : -1;
+      if (bin[u] >= 0) atomicAdd(&s_hist[bin[u]], 1);
+    }
+    __syncthreads();
+    hist_locate<THREADS>(k, sh);
+    const int sel = sh.sel;
+    const int superset = (k - sh.need) + sh.cnt;                // keys in bins >= sel
+    if (superset <= YP_SORT_MAX) {
+#pragma unroll
+      for (int u = 0; u < YP_CC_PRE; ++u)
+        if (bin[u] >= sel) {
+          const int slot = lds_append_slot(&sh.fill);
+          sh.tmp[slot] = src.pre[u];
+          tbox[slot] = preb[u];
+        }
+      __syncthreads();
+      constexpr int G = THREADS / YP_SORT_MAX;
+      const int j = t % YP_SORT_MAX, g = t / YP_SORT_MAX;
+      u64 mine = 0;
+      if (j < superset) {
+        mine = sh.tmp[j];
+        int c = 0;
+#pragma unroll 8
+        for (int i = g; i < superset; i += G) c += sh.tmp[i] > mine ? 1 : 0;
+        if (c) atomicAdd(&sh.rank[j], c);
+      }
+      __syncthreads();
+      if (t < superset) {
+        const int r = sh.rank[t];
+        sh.key[r] = mine;
+        sbox[r] = tbox[t];
+        sh.rank[t] = 0;
+      }
+      m = superset;
+    }
+    __syncthreads();
+  }
   STAMP(2);
+  if (m < 0) {
+#ifdef YP_STAMPS
+  select_topk_sorted<THREADS>(src, n, p.top_k, sh, stage, YP_STAGE_CAP, dbg_);
+#else
+  select_topk_sorted<THREADS>(src, n, p.top_k, sh, stage, YP_STAGE_CAP);       // detection.py:186
+#endif
   if (t < YP_SORT_MAX) ssup[t] = 0;
-  {
     // the selected keys' boxes (detection.py:187, :79): whoever holds a key >= the k-th largest puts its box at
     // the key's rank
     const u64 kth = sh.key[k - 1];
@@ -791,8 +864,8 @@ __global__ __launch_bounds__(THREADS) void cc_nms_kernel(const NmsArgs p) {
       const u64 key = lk[(size_t)l * p.lcap + i];
       if (key >= kth) sbox[rank_desc(sh.key, k, key)] = lb[(size_t)l * p.lcap + i];
     }
-  }
   __syncthreads();
+  }
   STAMP(3);
   int pos, total;
   const bool keep = fast_nms_keep<THREADS>(sbox, ssup, s_wave_cnt, k, p.nms_thresh, pos, total);
@@ -1311,6 +1384,13 @@ static NmsArgs make_args(const yp_handle* h, int batch, const float* pred_offset
   a.A = h->cfg.num_anchors; a.nseg = h->nseg; a.top_k = h->cfg.top_k; a.max_dets = h->cfg.max_dets;
   a.sel_rows = h->sel_rows;
   a.nms_thresh = h->cfg.nms_thresh;
+  {
+    const float conf = h->cfg.conf_thresh > 0.0f ? h->cfg.conf_thresh : 0.0f;
+    const uint32_t cb = __builtin_bit_cast(uint32_t, conf);
+    a.sel_base = cb < 0x3F800000u ? cb : 0u;
+    a.sel_shift = 0;
+    while (((0x3F800000u - a.sel_base) >> a.sel_shift) > (uint32_t)(YP_RADIX_BINS - 1)) ++a.sel_shift;
+  }
   a.img_h = (float)h->cfg.img_h; a.img_w = (float)h->cfg.img_w;
   a.proto_h = (float)h->cfg.proto_h; a.proto_w = (float)h->cfg.proto_w;
   a.use_crop = h->cfg.use_cropped_mask;
