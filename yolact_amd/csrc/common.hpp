@@ -129,7 +129,10 @@ __device__ __forceinline__ void yp_sanitize(float a, float b, float img_size, bo
 
 #define YP_NLISTS 16       // candidate lists per image: one per class group (per-class mode), or the image's
                            // score_filter items dealt round-robin (cross-class mode)
-#define YP_CNT_STRIDE 32   // ints between two list counters: every counter has a 128-byte line of its own
+#define YP_CNT_STRIDE 32   // ints per list counter in the counter block (16 x 32 ints per image)
+// List l's counter inside its image's block: lists 2i and 2i+1 are the two halves of one 64-bit word - score_filter
+// adds to both with one atomic - and every word has 256 bytes of its own.
+#define YP_CNT_IDX(l) (((l) >> 1) * (2 * YP_CNT_STRIDE) + ((l) & 1))
                            // (agent-scope atomics on one line are served one after the other, ~10 ns each:
                            // tools/atomic_probe.hip)
 

@@ -759,7 +759,7 @@ __global__ __launch_bounds__(THREADS) void cc_nms_kernel(const NmsArgs p) {
   const float4* const lb = p.lbox + ((size_t)b * YP_NLISTS) * p.lcap;
   int32_t* const cnt_g = p.lcount + ((size_t)b * YP_NLISTS) * YP_CNT_STRIDE;
   int my_cnt = 0;
-  if (q == 0) my_cnt = cnt_g[l * YP_CNT_STRIDE];
+  if (q == 0) my_cnt = cnt_g[YP_CNT_IDX(l)];
   CcSrc src{lk, lb, p.lcap, s_cnt, {}};
   float4 preb[YP_CC_PRE];
 #pragma unroll
@@ -778,7 +778,7 @@ __global__ __launch_bounds__(THREADS) void cc_nms_kernel(const NmsArgs p) {
   if (q == 0) {
     my_cnt = (int)min((long long)my_cnt, p.lcap);   // (an anchor emits one key: the lists cannot overflow)
     s_cnt[l] = my_cnt;
-    if (my_cnt != 0) cnt_g[l * YP_CNT_STRIDE] = 0;  // ready for the next launch: this workgroup is the counter's only reader
+    if (my_cnt != 0) cnt_g[YP_CNT_IDX(l)] = 0;  // ready for the next launch: this workgroup is the counter's only reader
   }
   const int survivors = block_sum<THREADS>(part, sh.wtot);    // (its barriers also publish s_cnt[])
   int n = 0;
@@ -1044,11 +1044,12 @@ __device__ __forceinline__ void group_nms_body(const NmsArgs& p, int b, int g, G
   //    only reader; a reset by thread 0 while other waves still load the counter themselves would hand them a 0);
   //    everybody else gets the values through LDS.
   if (t == 0) {
-    const int c = p.lcount[li * YP_CNT_STRIDE];
+    int32_t* const my_count = p.lcount + (size_t)b * YP_NLISTS * YP_CNT_STRIDE + YP_CNT_IDX(g);
+    const int c = *my_count;
     const int o = p.ocount[(size_t)b * YP_CNT_STRIDE];
     gs.m_raw = c;
     gs.novf_raw = o;
-    if (c != 0) p.lcount[li * YP_CNT_STRIDE] = 0;
+    if (c != 0) *my_count = 0;
   }
   u64 key[KPT];
   float4 box[KPT];
@@ -1329,7 +1330,7 @@ __global__ __launch_bounds__(THREADS, YP_GROUP_MIN_WAVES) void group_nms_kernel(
   __shared__ GroupShared gs;
 #ifdef YP_EXP_NMS_NOP   // experiment build (timing only, wrong results): how long does the fill take with no NMS beside it?
   if (threadIdx.x == 0 && (int)blockIdx.x % p.ngroups == 0) p.num_det[(int)blockIdx.x / p.ngroups] = 0;
-  if (threadIdx.x == 0) p.lcount[((size_t)blockIdx.x / p.ngroups * YP_NLISTS + blockIdx.x % p.ngroups) * YP_CNT_STRIDE] = 0;
+  if (threadIdx.x == 0) p.lcount[((size_t)blockIdx.x / p.ngroups * YP_NLISTS) * YP_CNT_STRIDE + YP_CNT_IDX(blockIdx.x % p.ngroups)] = 0;
   return;
 #endif
   const int b = (int)blockIdx.x / p.ngroups, g = (int)blockIdx.x - b * p.ngroups;

@@ -181,15 +181,18 @@ __global__ __launch_bounds__(YP_WAVE, YP_SF_MIN_WAVES) void score_filter_kernel(
     const int t_end = (int)(((long long)(part + 1) * p.ntiles) / p.parts);
     int nbuf = 0;    // keys parked in s_key
     int nsurv = 0;   // anchors past the confidence filter
-    // The parked keys leave for the image's lists, 64 at a time: every lane takes one key, fetches its anchor's
-    // prior and offsets, and - while those loads are in flight - the wave reserves slots with ONE atomic
-    // instruction: the lowest lane of every list that occurs among the 64 keys adds that list's share, all of them
-    // in the same instruction.  (One instruction per list, issued back to back, cost 8 us per launch at config 2
-    // and 30 at config 4: a wave's returning agent-scope atomics are served one after the other, ~0.5 us each;
-    // tools/atomic_probe.hip.)
-    // A batch of up to 64 parked keys on its way out, in two halves so that the memory latencies of the first -
-    // the slot atomics and the gather of prior and offsets - can pass while the wave does something else.
-    struct Batch { bool has; u64 key; float4 pr, of; int lst, base, leader, rank; };
+    // The parked keys leave for the image's lists.  Slots come from ONE atomic instruction per flush, however many
+    // keys are parked: lane i first counts the parked keys of list i (ballots), then lanes 0..7 add the totals of
+    // lists 2i and 2i+1 to the two halves of one 64-bit counter word.  A wave's returning agent-scope atomics are
+    // served one after the other, ~0.2-0.5 us each (tools/atomic_probe.hip), so what a flush costs is the number
+    // of active lanes in its atomic instructions: one instruction per list cost 8 us per launch at config 2 and 30
+    // at config 4; one instruction per 64 keys with a lane per list 3 us and ~25; this form at most 8 lanes per
+    // flush.  (Packing the counters closer - 4 to 64 bytes apart - changed nothing: the cost is per lane, not per
+    // line.)  The keys then go out 64 at a time: every lane takes one key, fetches its anchor's prior and offsets -
+    // the first batch's gather is issued BEFORE the atomic, the next batch's before the current one is stored -
+    // decodes the box and stores key and box at its list's running base + its rank among the batch's keys of
+    // that list.
+    struct Batch { bool has; u64 key; float4 pr, of; int lst; };
     auto batch_issue = [&](int l0) -> Batch {   // keys s_key[l0 .. min(l0 + 64, nbuf)); no wait inside
       Batch q;
       q.has = l0 + lane < nbuf;
@@ -197,11 +200,7 @@ __global__ __launch_bounds__(YP_WAVE, YP_SF_MIN_WAVES) void score_filter_kernel(
       const int anchor = min(yp_seg_key_anchor(q.key), p.A - 1);
       q.pr = p.priors[anchor];
       q.of = p.off[(size_t)b * p.A + anchor];
-#ifdef YP_EXP_ONE_ATOMIC   // experiment build (timing only, wrong results): what do the per-list atomics cost?
-      if (true) {
-#else
       if (MODE == YP_NMS_CROSS_CLASS) {
-#endif
         q.lst = part & (YP_NLISTS - 1);
       } else {
         // (c - 1) % ngroups without the integer division: (x + 0.5) / n is at least 0.5 / n away from an
@@ -209,24 +208,10 @@ __global__ __launch_bounds__(YP_WAVE, YP_SF_MIN_WAVES) void score_filter_kernel(
         const int c1 = yp_seg_key_class(q.key) - 1;
         q.lst = c1 - (int)(((float)c1 + 0.5f) * ginv) * p.ngroups;
       }
-      int32_t* const cnt = p.lcount + ((size_t)b * YP_NLISTS) * YP_CNT_STRIDE;
-      u64 rest = __ballot(q.has);
-      int share = 0;
-      q.base = 0; q.leader = 0; q.rank = 0;
-      while (rest != 0ull) {   // (one trip in cross-class mode; no memory operation inside)
-        const int l1 = __builtin_ctzll(rest);
-        const int g1 = __builtin_amdgcn_readlane(q.lst, l1);
-        const u64 mm = __ballot(q.lst == g1) & rest;
-        if (q.has && q.lst == g1) { q.leader = l1; q.rank = __popcll(mm & lt_mask); }
-        if (lane == l1) share = __popcll(mm);
-        rest &= ~mm;
-      }
-      if (share != 0) q.base = __hip_atomic_fetch_add(cnt + q.lst * YP_CNT_STRIDE, share, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       return q;
     };
-    auto batch_commit = [&](const Batch& q) {
+    auto batch_commit = [&](const Batch& q, int slot) {
       const float4 box = yp_decode(q.pr, q.of);                                           // detection.py:79
-      const int slot = __shfl(q.base, q.leader) + q.rank;
       if (q.has) {
         if (slot < p.lcap) {
           const size_t o = ((size_t)b * YP_NLISTS + q.lst) * p.lcap + slot;
@@ -244,16 +229,55 @@ __global__ __launch_bounds__(YP_WAVE, YP_SF_MIN_WAVES) void score_filter_kernel(
     };
     auto flush = [&]() {   // wave-uniform: everything parked leaves now, and the wave waits for it
       __builtin_amdgcn_wave_barrier();
-#ifdef YP_EXP_NO_FLUSH   // experiment build (timing only, no candidates leave): what does the flush cost?
-      nbuf = 0;
-#endif
-      for (int l0 = 0; l0 < nbuf; l0 += YP_WAVE) batch_commit(batch_issue(l0));
+      if (nbuf == 0) return;
+      int tot = 0;         // lane i < YP_NLISTS: parked keys of list i
+      if (MODE == YP_NMS_CROSS_CLASS) {
+        if (lane == (part & (YP_NLISTS - 1))) tot = nbuf;
+      } else {
+        for (int l0 = 0; l0 < nbuf; l0 += YP_WAVE) {
+          const int c1 = yp_seg_key_class(s_key[min(l0 + lane, nbuf - 1)]) - 1;
+          const int lst = l0 + lane < nbuf ? c1 - (int)(((float)c1 + 0.5f) * ginv) * p.ngroups : -1;
+          for (int i = 0; i < p.ngroups; ++i) {
+            const u64 mm = __ballot(lst == i);
+            if (lane == i) tot += __popcll(mm);
+          }
+        }
+      }
+      Batch q = batch_issue(0);
+      const int t_lo = __shfl(tot, (2 * lane) & 63), t_hi = __shfl(tot, (2 * lane + 1) & 63);
+      u64 got = 0;
+      if (lane < YP_NLISTS / 2 && (t_lo | t_hi) != 0)
+        got = __hip_atomic_fetch_add(reinterpret_cast<u64*>(p.lcount + (size_t)b * YP_NLISTS * YP_CNT_STRIDE + YP_CNT_IDX(2 * lane)),
+                                     (u64)(uint32_t)t_lo | ((u64)(uint32_t)t_hi << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int g_lo = __shfl((int)(uint32_t)got, lane >> 1), g_hi = __shfl((int)(uint32_t)(got >> 32), lane >> 1);
+      int run = (lane & 1) ? g_hi : g_lo;   // lane i < YP_NLISTS: the next free slot of list i
+      for (int l0 = 0; l0 < nbuf; l0 += YP_WAVE) {
+        Batch nx = q;
+        if (l0 + YP_WAVE < nbuf) nx = batch_issue(l0 + YP_WAVE);
+        int rank = 0, add = 0;
+        if (MODE == YP_NMS_CROSS_CLASS) {
+          const u64 mm = __ballot(q.has);
+          rank = __popcll(mm & lt_mask);
+          if (lane == q.lst) add = __popcll(mm);   // (q.lst is the same in every lane)
+        } else {
+          for (int i = 0; i < p.ngroups; ++i) {
+            const u64 mm = __ballot(q.has && q.lst == i);
+            if (q.lst == i) rank = __popcll(mm & lt_mask);
+            if (lane == i) add = __popcll(mm);
+          }
+        }
+        const int slot = __shfl(run, q.lst) + rank;
+        run += add;
+        batch_commit(q, slot);
+        q = nx;
+      }
       nbuf = 0;
     };
     // (Tried: the keys of all tiles but the last issued - atomics, gather - when the last tile's processing starts and
     //  committed when it ends, so that only the last tile's handful waits at the item's end: 55.3 us per launch at
     //  config 2 against 51.4 with the one flush at the end; flushing synchronously before the last tile: 52.7.  For
-    //  reference: 44.7 with no flush at all, 48.4 with one atomic per flush instead of one per list.)
+    //  reference, with the per-batch atomics of that time: 44.7 with no flush at all, 48.4 with one atomic lane per
+    //  batch instead of one per list.)
     if (FAST) issue_loads(b, t_begin, t_begin < t_end);
 
     for (int tix = t_begin; tix < t_end; ++tix) {
