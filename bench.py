@@ -383,9 +383,12 @@ def main():
             "timing": "HIP events on the launch stream, this run",
             # north_star: "MFMA utilisation for mask assembly is reported"
             "mfma_util": 0.0,
-            "mfma_note": "mask_assemble issues no MFMA: the reference's dense [P,32]x[32,N] product is ~99% outside the crop "
-                         "boxes at this workload (box_coverage), so the kernel evaluates only (8x8 tile, detection) pairs that "
-                         "meet - ~2 per wave - as K-ordered fma chains; DESIGN.md section 5 holds the measured MFMA comparison",
+            "mfma_note": "no kernel of the shipped path issues MFMA. Measured, not argued (profiles/r03/gc_mfma_experiment.md): the one "
+                         "GEMM-shaped piece, F4's grad_coef ([rows x pixels] x [pixels x 32]), was built on v_mfma_f32_32x32x2_f32 behind "
+                         "-DYP_EXP_GC_MFMA and took 177.5 us against the fma-chain kernel's 72.5 us at 13 % box coverage, matrix cores "
+                         "busy 6.8 % of the SIMD cycles - the A operand has to be laid out dense and two thirds of it are zeros between "
+                         "the crop boxes. mask_assemble's K=32 contraction has the same shape problem (--box-coverage 0.13: 43 us, "
+                         "still latency/HBM-bound) and a fixed K-ordered fma chain as its arithmetic contract",
         },
         "gather_ms": None if gather_ms is None else round(gather_ms, 3),
         "gather_note": None if gather_ms is None else "this rank's outputs device -> pinned host, max over ranks; not part of value",

@@ -3,10 +3,12 @@
 # Each rocprofv3 pass is its own run (the PMC passes never share a run with tracing options).
 set -e
 export TMPDIR=/tmp
-OUT=gpurun_out/prof_${1:-r02}
+# usage: tools/gpu_profile.sh <tag> <per_class|cc> [extra bench.py arguments, e.g. --config 4]
+OUT=gpurun_out/prof_${1:-r03}
 MODE=${2:-per_class}
+shift; shift || true
 rm -rf "$OUT"; mkdir -p "$OUT"
-CMD="python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --skip-same-buffer --nms-mode $MODE"
+CMD="python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --skip-same-buffer --nms-mode $MODE $*"
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- $CMD > "$OUT/trace.log" 2>&1
 timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -- $CMD > "$OUT/fetch.log" 2>&1
 timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -- $CMD > "$OUT/write.log" 2>&1
