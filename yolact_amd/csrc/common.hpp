@@ -133,8 +133,6 @@ __device__ __forceinline__ void yp_sanitize(float a, float b, float img_size, bo
 // List l's counter inside its image's block: lists 2i and 2i+1 are the two halves of one 64-bit word - score_filter
 // adds to both with one atomic - and every word has 256 bytes of its own.
 #define YP_CNT_IDX(l) (((l) >> 1) * (2 * YP_CNT_STRIDE) + ((l) & 1))
-                           // (agent-scope atomics on one line are served one after the other, ~10 ns each:
-                           // tools/atomic_probe.hip)
 
 struct yp_scratch {
   u64* lkeys;           // [batch][YP_NLISTS][lcap] candidate keys, appended by score_filter in no particular order

@@ -16,7 +16,7 @@
 //                one list per group, so a group's workgroup loads its list length and its candidates in
 //                ONE round trip, keeps them in registers (up to 4 per thread), buckets the keys by class
 //                in LDS, ranks and suppresses thread-per-candidate;
-//                the group that finishes last (arrival counter, agent-scope release/acquire) then
+//                the group that finishes last (write-through stores, arrival counter, one invalidate) then
 //                does the image's cross-class top max_dets selection and writes its output rows
 // Both kernels carry the zero-fill of the mask rows as extra workgroups behind the NMS workgroups
 // (fill_block): it depends on nothing the NMS computes, HBM is idle while these latency-bound
