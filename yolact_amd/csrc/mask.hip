@@ -65,6 +65,21 @@ __global__ __launch_bounds__(YP_MASK_BLOCK) void mask_assemble_kernel(const Mask
   // The tile's prototypes: thread t's float4 number i is quad (t & 7) of the tile's pixel
   // (2i + (t >> 7), (t & 127) >> 3) - every load instruction of the workgroup covers two whole tile rows
   // (2 x 2 KiB).  Pixels past the image's edge are read from the edge pixel instead (and never used).
+  // First in the queue: the crop edges and anchors of the image's detections (lane l: detection g*64 + l) - vector
+  // loads return in order, so the relevance test below waits for these only, not for the prototypes behind them.
+  const int lane = t & 63;
+  float4 cbv[NG];
+  int anch[NG];      // lane l: anchor of detection g*64 + l (same round trip as its crop edges)
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    cbv[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+    anch[g] = 0;
+    if (g * 64 < p.sel_rows) {
+      const int nc = min(g * 64 + lane, p.sel_rows - 1);
+      cbv[g] = p.crop[(size_t)b * p.sel_rows + nc];
+      if (p.anchor) anch[g] = p.anchor[(size_t)b * p.sel_rows + nc];
+    }
+  }
   nat4 x[YP_MASK_DIM / 4];
   {
     const int pcol = min(col0 + ((t & 127) >> 3), p.pw - 1);
@@ -80,24 +95,20 @@ __global__ __launch_bounds__(YP_MASK_BLOCK) void mask_assemble_kernel(const Mask
   // quadrant's rows and columns (a superset test: the per-pixel compares below decide the values); the
   // ballots give a bit per detection.  Everything wave-uniform is kept in SGPRs on purpose (readfirstlane
   // where the compiler cannot prove it), so that walking the bits is scalar work.
-  const int lane = t & 63;
   const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
   const int qr0 = row0 + (wv >> 1) * 8, qc0 = col0 + (wv & 1) * 8;   // the quadrant's first pixel
   const int r = qr0 + (lane >> 3), c = qc0 + (lane & 7);             // this lane's pixel
   const bool live = r < p.ph && c < p.pw;
   u64 rel[NG];
-  int anch[NG];      // lane l: anchor of detection g*64 + l (same round trip as its crop edges)
 #pragma unroll
-  for (int g = 0; g < NG; ++g) { rel[g] = 0ull; anch[g] = 0; }
+  for (int g = 0; g < NG; ++g) rel[g] = 0ull;
   if (qr0 < p.ph && qc0 < p.pw) {
     const float fr0 = (float)qr0, fr1 = (float)min(qr0 + 7, p.ph - 1), fc0 = (float)qc0, fc1 = (float)min(qc0 + 7, p.pw - 1);
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
       if (g * 64 < p.sel_rows) {
         const int n = g * 64 + lane;
-        const int nc = min(n, p.sel_rows - 1);
-        const float4 cb = p.crop[(size_t)b * p.sel_rows + nc];
-        if (p.anchor) anch[g] = p.anchor[(size_t)b * p.sel_rows + nc];
+        const float4 cb = cbv[g];
         const bool hit = (n < N) && (fc1 >= cb.x) && (fc0 < cb.y) && (fr1 >= cb.z) && (fr0 < cb.w);
         const u64 m = __ballot(hit);
         rel[g] = ((u64)(uint32_t)__builtin_amdgcn_readfirstlane((int)(m >> 32)) << 32) |
@@ -110,6 +121,27 @@ __global__ __launch_bounds__(YP_MASK_BLOCK) void mask_assemble_kernel(const Mask
 #pragma unroll
   for (int g = 0; g < NG; ++g) any_rel |= rel[g];
   if (__syncthreads_or(any_rel != 0ull) == 0) return;
+
+  // The FIRST detection the wave visits: its wave-uniform data - 32 coefficients and 4 crop edges - are fetched
+  // into one VGPR now (lane k < 32: coefficient k of the detection's row, by its anchor, straight from
+  // pred_mask_coef, detection.py:206; lanes 32..35: its crop edges), so that the round trip passes during the LDS
+  // transpose below instead of after it.  (The later visits fetch theirs by scalar loads when their turn comes:
+  // vector loads for them would wait behind the stores of the visit before - one counter for both on gfx9.)
+  int n_first = -1;                             // wave-uniform
+#pragma unroll
+  for (int g = NG - 1; g >= 0; --g) if (rel[g] != 0ull) n_first = g * 64 + __builtin_ctzll(rel[g]);
+  float firstv = 0.0f;
+  if (n_first >= 0) {
+    int crow = n_first;
+    if (p.anchor) {
+#pragma unroll
+      for (int g = 0; g < NG; ++g) if ((n_first >> 6) == g) crow = __builtin_amdgcn_readlane(anch[g], n_first & 63);
+    }
+    const float* const src = lane < YP_MASK_DIM
+        ? p.coef + ((size_t)b * (p.anchor ? (size_t)p.A : (size_t)p.sel_rows) + crow) * YP_MASK_DIM + lane
+        : reinterpret_cast<const float*>(p.crop + (size_t)b * p.sel_rows + n_first) + (lane & 3);
+    if (lane < YP_MASK_DIM + 4) firstv = *src;
+  }
 
   float pr[YP_MASK_DIM];
   {
@@ -153,9 +185,41 @@ __global__ __launch_bounds__(YP_MASK_BLOCK) void mask_assemble_kernel(const Mask
   const uint32_t voff = (uint32_t)pix * 4u;
   const uint32_t rstride = (uint32_t)p.P * 4u;     // yp_create bounds sel_rows * P * 4 below 2^32
   const bool plain = !NT_STORE && brow == nullptr;
+  // One visited detection: crop test per pixel, K-ordered fma chain, sigmoid, store inside the box.
+  auto visit = [&](int n, const float4 cb, auto coef_at) {
+    // mask_left & mask_right & mask_bottom & mask_top, float compares (utils/utils.py:125-130)
+    const bool in = live && (fcol >= cb.x) && (fcol < cb.y) && (frow >= cb.z) && (frow < cb.w);
+    if (__ballot(in) == 0ull) return;          // the superset test let it through: the zeros stand
+    float acc = 0.0f;
+#pragma unroll
+    for (int k = 0; k < YP_MASK_DIM; ++k) acc = __builtin_fmaf(pr[k], coef_at(k), acc);   // detection.py:89
+    const float sg = yp_sigmoid(acc);                                                    // detection.py:90
+    const float v = yp_clip(in ? sg : 0.0f, 0.0f, 1.0f);                                  // utils.py:133, L105
+    // only the pixels inside the box are written (the others hold their zeros): in a tile that is most of
+    // the lanes, and the neighbouring tiles write the rest of the cache line
+    if (in) {
+      if (plain) {
+        const uint32_t vo = voff + (uint32_t)n * rstride;
+        asm volatile("global_store_dword %0, %1, %2" ::"v"(vo), "v"(v), "s"(orow) : "memory");
+      } else {
+        if (NT_STORE) __builtin_nontemporal_store(v, orow + (size_t)n * p.P + pix); else orow[(size_t)n * p.P + pix] = v;
+        if (brow) brow[(size_t)n * p.P + pix] = v > p.mask_threshold ? 1 : 0;                // train.py:497
+      }
+    }
+  };
+  if (n_first >= 0) {
+    const int fv = __builtin_bit_cast(int, firstv);
+    float4 cb;
+    cb.x = __builtin_bit_cast(float, __builtin_amdgcn_readlane(fv, YP_MASK_DIM + 0));
+    cb.y = __builtin_bit_cast(float, __builtin_amdgcn_readlane(fv, YP_MASK_DIM + 1));
+    cb.z = __builtin_bit_cast(float, __builtin_amdgcn_readlane(fv, YP_MASK_DIM + 2));
+    cb.w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(fv, YP_MASK_DIM + 3));
+    visit(n_first, cb, [&](int k) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(fv, k)); });
+  }
 #pragma unroll
   for (int g = 0; g < NG; ++g) {
     u64 w = rel[g];                            // wave-uniform
+    if ((n_first >> 6) == g) w &= w - 1ull;    // (the first one is done)
     while (w != 0ull) {
       const int n = g * 64 + __builtin_ctzll(w);
       w &= w - 1ull;
@@ -165,29 +229,9 @@ __global__ __launch_bounds__(YP_MASK_BLOCK) void mask_assemble_kernel(const Mask
       // stores.
       float4 cb;
       cb.x = crop_c[4 * n + 0]; cb.y = crop_c[4 * n + 1]; cb.z = crop_c[4 * n + 2]; cb.w = crop_c[4 * n + 3];
-      // the detection's coefficient row: by its anchor, straight from pred_mask_coef (a wave-uniform index: the
-      // lane that tested detection n holds the anchor)
       const int crow = p.anchor ? __builtin_amdgcn_readlane(anch[g], n & 63) : n;
       cfloat* const cf = coef_c + (size_t)crow * YP_MASK_DIM;
-      // mask_left & mask_right & mask_bottom & mask_top, float compares (utils/utils.py:125-130)
-      const bool in = live && (fcol >= cb.x) && (fcol < cb.y) && (frow >= cb.z) && (frow < cb.w);
-      if (__ballot(in) == 0ull) continue;      // the superset test let it through: the zeros stand
-      float acc = 0.0f;
-#pragma unroll
-      for (int k = 0; k < YP_MASK_DIM; ++k) acc = __builtin_fmaf(pr[k], cf[k], acc);       // detection.py:89
-      const float sg = yp_sigmoid(acc);                                                    // detection.py:90
-      const float v = yp_clip(in ? sg : 0.0f, 0.0f, 1.0f);                                  // utils.py:133, L105
-      // only the pixels inside the box are written (the others hold their zeros): in a tile that is most of
-      // the lanes, and the neighbouring tiles write the rest of the cache line
-      if (in) {
-        if (plain) {
-          const uint32_t vo = voff + (uint32_t)n * rstride;
-          asm volatile("global_store_dword %0, %1, %2" ::"v"(vo), "v"(v), "s"(orow) : "memory");
-        } else {
-          if (NT_STORE) __builtin_nontemporal_store(v, orow + (size_t)n * p.P + pix); else orow[(size_t)n * p.P + pix] = v;
-          if (brow) brow[(size_t)n * p.P + pix] = v > p.mask_threshold ? 1 : 0;                // train.py:497
-        }
-      }
+      visit(n, cb, [&](int k) { return cf[k]; });
     }
   }
 }
