@@ -33,6 +33,9 @@ struct MaskArgs {
 
 #define YP_MASK_BLOCK 256
 #define YP_MASK_TILE 16  // a workgroup owns a 16 x 16 tile of proto pixels: four waves, an 8 x 8 quadrant each
+#ifndef YP_MASK_PRE
+#define YP_MASK_PRE 1    // detections per wave whose coefficients are prefetched before the LDS transpose
+#endif                   // (1 / 2 / 3 / 4 / 6: 22.9 / 22.9 / 23.1 / 23.1 / 23.2 us at config 2, 41.3 / 41.6 / 41.8 / 42.4 / 43.5 at 13 % box coverage)
 #define YP_MASK_ROW4 3   // float4 per pixel row in LDS: 2 of data + 1 of padding (48-byte stride: conflict-free b128 reads)
 
 // One workgroup = one 16 x 16 tile of one image's prototypes; wave w owns the quadrant (w >> 1, w & 1), lane l
@@ -122,25 +125,33 @@ __global__ __launch_bounds__(YP_MASK_BLOCK) void mask_assemble_kernel(const Mask
   for (int g = 0; g < NG; ++g) any_rel |= rel[g];
   if (__syncthreads_or(any_rel != 0ull) == 0) return;
 
-  // The FIRST detection the wave visits: its wave-uniform data - 32 coefficients and 4 crop edges - are fetched
-  // into one VGPR now (lane k < 32: coefficient k of the detection's row, by its anchor, straight from
-  // pred_mask_coef, detection.py:206; lanes 32..35: its crop edges), so that the round trip passes during the LDS
-  // transpose below instead of after it.  (The later visits fetch theirs by scalar loads when their turn comes:
-  // vector loads for them would wait behind the stores of the visit before - one counter for both on gfx9.)
-  int n_first = -1;                             // wave-uniform
+  // The first YP_MASK_PRE detections the wave visits: their wave-uniform data - 32 coefficients and 4 crop edges
+  // each - are fetched into one VGPR per detection now (lane k < 32: coefficient k of the detection's row, by its
+  // anchor, straight from pred_mask_coef, detection.py:206; lanes 32..35: its crop edges), so that the round trip
+  // passes during the LDS transpose below instead of after it.  (Later visits fetch theirs by scalar loads when
+  // their turn comes: vector loads for them would wait behind the stores of the visits before - one counter for
+  // both on gfx9.)
+  int npre[YP_MASK_PRE];                        // wave-uniform; -1: none
+  float prev[YP_MASK_PRE];
 #pragma unroll
-  for (int g = NG - 1; g >= 0; --g) if (rel[g] != 0ull) n_first = g * 64 + __builtin_ctzll(rel[g]);
-  float firstv = 0.0f;
-  if (n_first >= 0) {
-    int crow = n_first;
-    if (p.anchor) {
+  for (int u = 0; u < YP_MASK_PRE; ++u) {
+    int n = -1;
 #pragma unroll
-      for (int g = 0; g < NG; ++g) if ((n_first >> 6) == g) crow = __builtin_amdgcn_readlane(anch[g], n_first & 63);
+    for (int g = 0; g < NG; ++g)
+      if (n < 0 && rel[g] != 0ull) { n = g * 64 + __builtin_ctzll(rel[g]); rel[g] &= rel[g] - 1ull; }
+    npre[u] = n;
+    prev[u] = 0.0f;
+    if (n >= 0) {
+      int crow = n;
+      if (p.anchor) {
+#pragma unroll
+        for (int g = 0; g < NG; ++g) if ((n >> 6) == g) crow = __builtin_amdgcn_readlane(anch[g], n & 63);
+      }
+      const float* const src = lane < YP_MASK_DIM
+          ? p.coef + ((size_t)b * (p.anchor ? (size_t)p.A : (size_t)p.sel_rows) + crow) * YP_MASK_DIM + lane
+          : reinterpret_cast<const float*>(p.crop + (size_t)b * p.sel_rows + n) + (lane & 3);
+      if (lane < YP_MASK_DIM + 4) prev[u] = *src;
     }
-    const float* const src = lane < YP_MASK_DIM
-        ? p.coef + ((size_t)b * (p.anchor ? (size_t)p.A : (size_t)p.sel_rows) + crow) * YP_MASK_DIM + lane
-        : reinterpret_cast<const float*>(p.crop + (size_t)b * p.sel_rows + n_first) + (lane & 3);
-    if (lane < YP_MASK_DIM + 4) firstv = *src;
   }
 
   float pr[YP_MASK_DIM];
@@ -207,19 +218,20 @@ __global__ __launch_bounds__(YP_MASK_BLOCK) void mask_assemble_kernel(const Mask
       }
     }
   };
-  if (n_first >= 0) {
-    const int fv = __builtin_bit_cast(int, firstv);
-    float4 cb;
-    cb.x = __builtin_bit_cast(float, __builtin_amdgcn_readlane(fv, YP_MASK_DIM + 0));
-    cb.y = __builtin_bit_cast(float, __builtin_amdgcn_readlane(fv, YP_MASK_DIM + 1));
-    cb.z = __builtin_bit_cast(float, __builtin_amdgcn_readlane(fv, YP_MASK_DIM + 2));
-    cb.w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(fv, YP_MASK_DIM + 3));
-    visit(n_first, cb, [&](int k) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(fv, k)); });
-  }
+#pragma unroll
+  for (int u = 0; u < YP_MASK_PRE; ++u)
+    if (npre[u] >= 0) {
+      const int fv = __builtin_bit_cast(int, prev[u]);
+      float4 cb;
+      cb.x = __builtin_bit_cast(float, __builtin_amdgcn_readlane(fv, YP_MASK_DIM + 0));
+      cb.y = __builtin_bit_cast(float, __builtin_amdgcn_readlane(fv, YP_MASK_DIM + 1));
+      cb.z = __builtin_bit_cast(float, __builtin_amdgcn_readlane(fv, YP_MASK_DIM + 2));
+      cb.w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(fv, YP_MASK_DIM + 3));
+      visit(npre[u], cb, [&](int k) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(fv, k)); });
+    }
 #pragma unroll
   for (int g = 0; g < NG; ++g) {
-    u64 w = rel[g];                            // wave-uniform
-    if ((n_first >> 6) == g) w &= w - 1ull;    // (the first one is done)
+    u64 w = rel[g];                            // wave-uniform: what the prefetched visits left
     while (w != 0ull) {
       const int n = g * 64 + __builtin_ctzll(w);
       w &= w - 1ull;
