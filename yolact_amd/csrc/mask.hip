@@ -33,6 +33,9 @@ struct MaskArgs {
 
 #define YP_MASK_BLOCK 256
 #define YP_MASK_TILE 16  // a workgroup owns a 16 x 16 tile of proto pixels: four waves, an 8 x 8 quadrant each
+#ifndef YP_MASK_WAVES_PER_EU
+#define YP_MASK_WAVES_PER_EU 1   // no bound: 66 VGPRs, 7 waves per SIMD.  Bound to 8 (64 VGPRs) the kernel spills 4: 28.5 us against 22.9
+#endif
 #ifndef YP_MASK_PRE
 #define YP_MASK_PRE 1    // detections per wave whose coefficients are prefetched before the LDS transpose
 #endif                   // (1 / 2 / 3 / 4 / 6: 22.9 / 22.9 / 23.1 / 23.1 / 23.2 us at config 2, 41.3 / 41.6 / 41.8 / 42.4 / 43.5 at 13 % box coverage)
@@ -49,7 +52,7 @@ struct MaskArgs {
 // Workgroups of one image are placed on one XCD (the dispatcher deals consecutive workgroup ids
 // round-robin over the 8 XCDs), so the partial cache lines of neighbouring tiles merge in a single L2.
 template <bool NT_STORE, int NG>   // NG: 64-detection groups the kernel looks at (sel_rows <= 64 * NG)
-__global__ __launch_bounds__(YP_MASK_BLOCK) void mask_assemble_kernel(const MaskArgs p, int blocks_per_image, int batch, int by_xcd) {
+__global__ __launch_bounds__(YP_MASK_BLOCK, YP_MASK_WAVES_PER_EU) void mask_assemble_kernel(const MaskArgs p, int blocks_per_image, int batch, int by_xcd) {
   __shared__ float4 sproto[YP_MASK_BLOCK * YP_MASK_ROW4];
   typedef float nat4 __attribute__((ext_vector_type(4)));
   const int t = threadIdx.x;
