@@ -89,6 +89,9 @@ def parse_args(argv=None):
     ap.add_argument("--reference-layout", action="store_true",
                     help="the reference as shipped (detection.py:21-22,83,181): cross-class NMS, top_k 15, "
                          "300 zero-padded rows per image")
+    ap.add_argument("--reuse-outputs", action="store_true",
+                    help="with --reference-layout: what Detect(reuse_outputs=True) does - the output sets are zeroed once, "
+                         "before the timed region, and every step rewrites only the rows a detection can land in")
     return ap.parse_args(argv)
 
 
@@ -204,7 +207,7 @@ def main():
 
     top_k, max_dets, zero_pad = cfg.top_k, cfg.max_dets, False
     if args.reference_layout:
-        args.nms_mode, top_k, max_dets, zero_pad = "cc", 15, 300, True
+        args.nms_mode, top_k, max_dets, zero_pad = "cc", 15, 300, not args.reuse_outputs
 
     base = {
         "metric": METRIC, "value": 0.0, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -244,6 +247,8 @@ def main():
     NR = max(1, args.rotate_outputs)
     NI = max(1, args.rotate_inputs if args.rotate_inputs is not None else NR)
     outs = [pp.alloc_outputs(B) for _ in range(NR)]
+    if args.reuse_outputs:
+        outs = [{k: torch.zeros_like(v) for k, v in o.items()} for o in outs]
 
     def upload(n):
         dd = {k: torch.from_numpy(v).to(dev) for k, v in n.items()}
@@ -370,6 +375,7 @@ def main():
             "workload": f"BASELINE config {args.config}: {cfg.img_h}x{cfg.img_w}, {A} anchors, {C} classes, "
                         f"proto {ph}x{pw}x32, {shard}, conf {cfg.conf_thresh}, top_k {top_k}, "
                         f"max {max_dets} dets, nms_mode {args.nms_mode}" + (", 300 zero-padded rows" if zero_pad else "")
+                        + (", 300 rows in kept output sets zeroed once (Detect(reuse_outputs=True))" if args.reuse_outputs else "")
                         + (f", boxes scaled x{box_scale:.2f} for --box-coverage {args.box_coverage}" if args.box_coverage is not None else ""),
             "batch_per_gpu": B, "images_per_step": images_per_step, "nms_mode": args.nms_mode,
             "rotate_outputs": NR, "rotate_inputs": NI, "mean_survivors": float(np.mean(S)), "mean_dets": float(np.mean(N)),

@@ -236,6 +236,31 @@ def test_detect_wrapper_reference_layout(torch_cuda):
     compare(res2, ref2, exact_values=False, atol=TOL, label="Detect-per-class")
 
 
+def test_detect_with_kept_outputs_matches_fresh_outputs(torch_cuda):
+    """Detect(reuse_outputs=True): one output set per shape, zeroed once; three calls in a row on different inputs
+    (the second with fewer detections than the first) return what a fresh, fully zero-padded call returns - the rows
+    behind the written ones are still zero - and the same tensors every time."""
+    from yolact_amd import Detect, synth
+    torch = torch_cuda
+    cfg = synth.CONFIGS[2]
+    fresh = Detect(cfg.num_classes, 300, 100, cfg.conf_thresh, 0.5)
+    kept = Detect(cfg.num_classes, 300, 100, cfg.conf_thresh, 0.5, reuse_outputs=True)
+    ptrs = None
+    for first, mode in ((0, "planted"), (4, "random_init"), (8, "planted")):
+        net, shp = synth.make_batch(cfg, batch=2, first_image=first, mode=mode)
+        dev = {k: torch.from_numpy(v).cuda() for k, v in net.items()}
+        a = fresh(dev, shp)
+        b = kept(dev, shp)
+        torch.cuda.synchronize()
+        assert a["detection_masks"].shape == (2, 300, 138, 138)
+        for k in a:
+            assert torch.equal(a[k], b[k]), (first, k)
+        assert (b["num_detections"] == 0).all() == (mode == "random_init")
+        now = {k: v.data_ptr() for k, v in b.items()}
+        assert ptrs is None or now == ptrs
+        ptrs = now
+
+
 def test_full_size_batch32_properties_and_oracle(torch_cuda):
     """BASELINE config 2 at its full size (batch 32): bit-exact against the C oracle, plus the
     size-independent properties of the path: idempotence, image-permutation equivariance,

@@ -178,11 +178,19 @@ class Detect(object):
     ("cc" | "per_class"), ``top_k``, ``max_dets`` rows (compact, un-padded masks unless
     ``zero_pad_masks``), ``nms_thresh`` forwarded as the IoU threshold, ``mask_threshold`` for an
     extra uint8 ``detection_bitmaps`` output (the callers' ``mask > 0.5``, train.py:497).
+
+    ``reuse_outputs=True`` (either mode; opt-in because it changes the lifetime of the results, not their
+    values): the 300 zero-padded rows cost 23 MB of zeros per image and call, of which at most ``top_k`` rows can
+    ever hold anything else.  With this option the object keeps ONE set of output tensors per input shape, zeroed
+    when it is created, and every call rewrites only the rows a detection can land in (the kernels zero those
+    themselves); the rows behind them are never written and stay zero.  The returned tensors are then views of
+    that set and are overwritten by the next call with the same shapes - clone what must outlive it.
     """
 
     def __init__(self, num_classes, max_output_size, per_class_max_output_size, conf_thresh, nms_thresh, *,
                  strict_reference: bool = True, nms_mode: str = "cc", top_k: int = 15, max_dets: int | None = None,
-                 zero_pad_masks: bool | None = None, mask_threshold: float | None = None, device=None):
+                 zero_pad_masks: bool | None = None, mask_threshold: float | None = None, device=None,
+                 reuse_outputs: bool = False):
         self.num_classes = num_classes
         self.nms_thresh = nms_thresh
         if nms_thresh <= 0:
@@ -206,7 +214,9 @@ class Detect(object):
             self.zero_pad_masks = bool(zero_pad_masks) if zero_pad_masks is not None else False
             self.mask_threshold = -1.0 if mask_threshold is None else float(mask_threshold)
         self.device = torch.device(device) if device is not None else None
+        self.reuse_outputs = bool(reuse_outputs)
         self._pp = {}
+        self._outs = {}       # reuse_outputs: (processor key, batch) -> the kept output set
 
     def _processor(self, key, build):
         pp = self._pp.get(key)
@@ -241,16 +251,25 @@ class Detect(object):
         if pp is None or pp.cfg.max_batch < B:
             if pp is not None:
                 pp.close()
+            self._outs = {k: v for k, v in self._outs.items() if k[0] != key}
             # (the library restores the caller's current device in every entry point, destroy included)
             pp = PostProcessor(PostConfig(
                 num_anchors=A, num_classes=C, proto_h=proto_h, proto_w=proto_w, img_h=H, img_w=W,
                 conf_thresh=float(self.conf_thresh), nms_thresh=float(self.iou_thresh), nms_mode=self.nms_mode,
                 top_k=int(self.top_k), max_dets=int(self.rows), use_cropped_mask=bool(use_cropped_mask),
-                zero_pad_masks=self.zero_pad_masks, mask_threshold=self.mask_threshold, max_batch=int(B),
-                device_id=dev.index))
+                # kept outputs: the padding rows are zero already and stay so, the handle must not rewrite them
+                zero_pad_masks=self.zero_pad_masks and not self.reuse_outputs, mask_threshold=self.mask_threshold,
+                max_batch=int(B), device_id=dev.index))
             self._pp[key] = pp
         with torch.cuda.device(dev):
-            out = pp.run(box_p, class_p, coef_p, anchors, proto_p)
+            kept = None
+            if self.reuse_outputs:
+                kept = self._outs.get((key, B))
+                if kept is None:
+                    kept = {k: torch.zeros_like(v) for k, v in
+                            pp.alloc_outputs(B, bitmaps=self.mask_threshold >= 0).items()}
+                    self._outs[(key, B)] = kept
+            out = pp.run(box_p, class_p, coef_p, anchors, proto_p, out=kept)
         result = {'detection_boxes': out['detection_boxes'], 'detection_classes': out['detection_classes'],
                   'detection_scores': out['detection_scores'], 'detection_masks': out['detection_masks'],
                   'num_detections': out['num_detections'],
