@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define YP_VERSION 300 /* 0.3.0 */
+#define YP_VERSION 310 /* 0.3.1 */
 
 enum {
   YP_OK = 0,
@@ -119,6 +119,31 @@ int yp_run(yp_handle* h, int32_t batch,
            float* det_masks, uint8_t* det_bitmaps,
            int32_t* num_det, int32_t* kept_anchor_idx,
            void* hip_stream);
+
+/* Output sets the library keeps track of.  NO COUNTERPART IN THE REFERENCE (its tf.zeros + scatter allocate fresh
+ * tensors per call, detection.py:65-68,109-113): it is for callers that own a few output sets and reuse them - a serving
+ * loop, an evaluation loop that consumes each result before the next batch.  yp_run must assume that det_masks holds
+ * anything and writes every row (at config 2: 244 MB of zeros per batch for ~3 MB of mask values).  A yp_kept remembers
+ * what the last call wrote into ONE set of mask buffers - the crop boxes of its detections - so that the next call
+ * clears exactly those pixels and writes its own: same results, bit for bit, without the refill.
+ *   yp_kept_create   device memory for the record (2 x max_batch x (rows x 16 + 4) bytes), allocated here, once
+ *   yp_run_kept      yp_run on a tracked set.  The FIRST call with a yp_kept zero-fills the mask buffers completely
+ *                    (every row yp_run would write, the padding rows of zero_pad_masks included) and binds the yp_kept
+ *                    to these det_masks / det_bitmaps pointers and to this batch size; later calls must pass the same
+ *                    pointers and batch (YP_EINVAL otherwise) and must not be overlapped with each other.  Nobody else
+ *                    may write the mask buffers in between.  det_masks must not be NULL.
+ *   yp_kept_reset    forget the record: the next call refills (after the caller wrote into the buffers itself) */
+typedef struct yp_kept yp_kept;
+int yp_kept_create(yp_handle* h, yp_kept** out);
+int yp_kept_destroy(yp_kept* k);
+int yp_kept_reset(yp_kept* k);
+int yp_run_kept(yp_handle* h, yp_kept* k, int32_t batch,
+                const float* pred_offset, const float* pred_cls, const float* pred_mask_coef,
+                const float* priors, const float* proto,
+                float* det_boxes, float* det_classes, float* det_scores,
+                float* det_masks, uint8_t* det_bitmaps,
+                int32_t* num_det, int32_t* kept_anchor_idx,
+                void* hip_stream);
 
 /* yp_run without a handle and without any allocation.  NO COUNTERPART IN THE REFERENCE: it is for
  * callers that cannot allocate device memory - code under HIP graph capture, tight serving loops,

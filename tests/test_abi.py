@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     assert set(syms) == set(_lib.EXPORTS), (syms, _lib.EXPORTS)
     for s in syms:
         assert hasattr(L, s), s
-    assert L.yp_version() == 300
+    assert L.yp_version() == 310
 
 
 def test_config_struct_matches_header():

@@ -236,6 +236,91 @@ def test_detect_wrapper_reference_layout(torch_cuda):
     compare(res2, ref2, exact_values=False, atol=TOL, label="Detect-per-class")
 
 
+@pytest.mark.parametrize("mode,top_k,max_dets,zero_pad,thr", [("per_class", 200, 100, False, -1.0), ("cc", 15, 300, True, -1.0),
+                                                              ("cc", 200, 100, False, 0.5), ("per_class", 200, 40, True, 0.5)])
+def test_tracked_output_set_equals_fresh_runs(torch_cuda, mode, top_k, max_dets, zero_pad, thr):
+    """yp_run_kept: one tracked output set through five runs on different inputs - many detections, none at all, the
+    first batch again, larger boxes, other images - equals yp_run into fresh buffers full of garbage every time, bit
+    for bit, masks and bitmaps included: what the run before wrote outside this run's boxes has been cleared, nothing
+    else was touched."""
+    from yolact_amd import PostConfig, PostProcessor, synth
+    torch = torch_cuda
+    cfg = synth.CONFIGS[2]
+    B = 3
+    pp = None
+    kept = None
+    seq = [(0, "planted", 1.0), (4, "random_init", 1.0), (0, "planted", 1.0), (8, "planted", 3.0), (12, "planted_soft", 1.0)]
+    for first, gen, scale in seq:
+        net, shp = synth.make_batch(cfg, batch=B, first_image=first, mode=gen)
+        if scale != 1.0:
+            net["pred_offset"][..., 2:] += np.float32(np.log(scale) / 0.2)      # utils/utils.py:202: w = pw * exp(dw * 0.2)
+        A, C = net["pred_cls"].shape[1:]
+        if pp is None:
+            pp = PostProcessor(PostConfig(A, C, 138, 138, cfg.img_h, cfg.img_w, conf_thresh=cfg.conf_thresh, nms_mode=mode,
+                                          top_k=top_k, max_dets=max_dets, zero_pad_masks=zero_pad, mask_threshold=thr, max_batch=B))
+            kept = pp.alloc_kept(B, bitmaps=thr >= 0)
+            for v in kept.values():
+                v.fill_(7)                                   # the first run must not rely on the buffers' contents
+        dev = {k: torch.from_numpy(v).cuda() for k, v in net.items()}
+        args = (dev["pred_offset"], dev["pred_cls"], dev["pred_mask_coef"], dev["priors"], dev["proto_out"])
+        fresh = pp.alloc_outputs(B, bitmaps=thr >= 0)
+        for v in fresh.values():
+            v.fill_(9)
+        pp.run(*args, out=fresh)
+        got = pp.run(*args, out=kept)
+        assert got is kept
+        pp.sync()
+        n = fresh["num_detections"]
+        rows = max_dets if zero_pad else None
+        for k in fresh:
+            a, b = fresh[k], kept[k]
+            if k in ("detection_masks", "detection_bitmaps") and rows is None:
+                # rows behind a detection-capable row are not part of the contract without zero padding: compare
+                # the rows the call defines (every row a detection can land in)
+                lim = min(max_dets, 256) if mode == "per_class" else min(max_dets, top_k, 256)
+                a, b = a[:, :lim], b[:, :lim]
+            assert torch.equal(a, b), (first, gen, k)
+        assert bool((n == 0).all()) == (gen == "random_init")
+    kept.close()
+    pp.close()
+
+
+def test_tracked_output_set_refuses_other_buffers_and_batches(torch_cuda):
+    from yolact_amd import PostConfig, PostProcessor, synth, _lib
+    torch = torch_cuda
+    cfg = synth.CONFIGS[2]
+    net, shp = synth.make_batch(cfg, batch=2)
+    A, C = net["pred_cls"].shape[1:]
+    pp = PostProcessor(PostConfig(A, C, 138, 138, cfg.img_h, cfg.img_w, conf_thresh=cfg.conf_thresh, nms_mode="cc", top_k=15,
+                                  max_dets=15, max_batch=2))
+    dev = {k: torch.from_numpy(v).cuda() for k, v in net.items()}
+    args = (dev["pred_offset"], dev["pred_cls"], dev["pred_mask_coef"], dev["priors"], dev["proto_out"])
+    kept = pp.alloc_kept(2)
+    pp.run(*args, out=kept)
+    own = kept["detection_masks"]
+    kept["detection_masks"] = torch.empty_like(own)                              # another buffer under the same record
+    with pytest.raises(_lib.YolactPostError, match="first call"):
+        pp.run(*args, out=kept)
+    kept["detection_masks"] = own
+    one = tuple(t if t.dim() == 2 and t.shape[0] == A else t[:1] for t in args)
+    small = type(kept)({k: v[:1] for k, v in kept.items()})
+    small._bind(kept._L, kept._k)
+    with pytest.raises(_lib.YolactPostError, match="bound to batch 2"):
+        pp.run(*one, out=small)
+    small._k = None
+    # the caller wrote into the masks: reset -> the next run refills
+    pp.sync()
+    kept["detection_masks"].fill_(5)
+    kept.reset()
+    pp.run(*args, out=kept)
+    pp.sync()
+    ref = pp.run(*args)
+    pp.sync()
+    assert torch.equal(kept["detection_masks"], ref["detection_masks"])
+    kept.close()
+    pp.close()
+
+
 def test_detect_with_kept_outputs_matches_fresh_outputs(torch_cuda):
     """Detect(reuse_outputs=True): one output set per shape, zeroed once; three calls in a row on different inputs
     (the second with fewer detections than the first) return what a fresh, fully zero-padded call returns - the rows

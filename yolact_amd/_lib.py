@@ -24,7 +24,8 @@ KERNEL_NAMES = ("score_filter", "nms", "mask_assemble")
 EXPORTS = ("yp_create", "yp_destroy", "yp_run", "yp_sync", "yp_last_survivors", "yp_profile_enable",
            "yp_profile_read", "yp_scratch_bytes", "yp_last_error", "yp_version", "yp_make_priors", "yp_run_static",
            "yp_masks_to_rle", "yp_rle_string", "yp_rle_strings", "yp_assemble_masks", "yp_assemble_masks_backward",
-           "yp_assemble_masks_backward_workspace", "yp_create_bounded", "yp_overflowed", "yp_masks_to_rle_sized")
+           "yp_assemble_masks_backward_workspace", "yp_create_bounded", "yp_overflowed", "yp_masks_to_rle_sized",
+           "yp_kept_create", "yp_kept_destroy", "yp_kept_reset", "yp_run_kept")
 
 
 class YpConfig(ctypes.Structure):
@@ -67,6 +68,14 @@ def load():
     L.yp_run.argtypes = [vp, ctypes.c_int32] + [vp] * 5 + [vp] * 7 + [vp]
     L.yp_run_static.restype = ctypes.c_int
     L.yp_run_static.argtypes = [ctypes.POINTER(YpConfig), ctypes.c_int32] + [vp] * 5 + [vp] * 7 + [vp]
+    L.yp_kept_create.restype = ctypes.c_int
+    L.yp_kept_create.argtypes = [vp, ctypes.POINTER(vp)]
+    L.yp_kept_destroy.restype = ctypes.c_int
+    L.yp_kept_destroy.argtypes = [vp]
+    L.yp_kept_reset.restype = ctypes.c_int
+    L.yp_kept_reset.argtypes = [vp]
+    L.yp_run_kept.restype = ctypes.c_int
+    L.yp_run_kept.argtypes = [vp, vp, ctypes.c_int32] + [vp] * 5 + [vp] * 7 + [vp]
     L.yp_sync.restype = ctypes.c_int
     L.yp_sync.argtypes = [vp]
     L.yp_last_survivors.restype = ctypes.c_int

@@ -289,6 +289,95 @@ extern "C" int yp_run(yp_handle* h, int32_t batch, const float* pred_offset, con
                    det_masks, det_bitmaps, num_det, kept_anchor_idx, st);
 }
 
+// ---- output sets the library keeps track of ----------------------------------------------------------
+// The record of one set of mask buffers: two slots of (crop edges per row, count per image), the one the last call
+// wrote and the one the next call writes; `side` says which is which.
+struct yp_kept {
+  int device;
+  int max_batch, sel_rows;
+  void* base;
+  float4* crop[2];
+  int32_t* num[2];
+  int side;              // the slot the NEXT call writes
+  bool fresh;            // nothing recorded yet: the next call refills the buffers
+  int batch;             // bound at the first call
+  const void* masks;     // ... as are the buffers
+  const void* bitmaps;
+};
+
+extern "C" int yp_kept_create(yp_handle* h, yp_kept** out) {
+  if (!h || !out) return fail(YP_EINVAL, "yp_kept_create: null argument");
+  *out = nullptr;
+  yp_kept* k = new (std::nothrow) yp_kept();
+  if (!k) return fail(YP_ENOMEM, "host allocation failed");
+  k->device = h->cfg.device_id; k->max_batch = h->cfg.max_batch; k->sel_rows = h->sel_rows;
+  YP_ON_DEVICE(k->device);
+  const size_t crop_bytes = align_up((size_t)k->max_batch * k->sel_rows * sizeof(float4), 256);
+  const size_t num_bytes = align_up((size_t)k->max_batch * sizeof(int32_t), 256);
+  const size_t total = 2 * (crop_bytes + num_bytes);
+  if (hipMalloc(&k->base, total) != hipSuccess) { delete k; return fail(YP_ENOMEM, "hipMalloc of %zu bytes failed", total); }
+  if (hipMemset(k->base, 0, total) != hipSuccess) { (void)hipFree(k->base); delete k; return fail(YP_EHIP, "hipMemset failed"); }
+  char* b = (char*)k->base;
+  k->crop[0] = (float4*)b; k->crop[1] = (float4*)(b + crop_bytes);
+  k->num[0] = (int32_t*)(b + 2 * crop_bytes); k->num[1] = (int32_t*)(b + 2 * crop_bytes + num_bytes);
+  k->side = 0; k->fresh = true; k->batch = 0; k->masks = nullptr; k->bitmaps = nullptr;
+  *out = k;
+  return YP_OK;
+}
+
+extern "C" int yp_kept_destroy(yp_kept* k) {
+  if (!k) return YP_OK;
+  YP_ON_DEVICE(k->device);
+  (void)hipFree(k->base);
+  delete k;
+  return YP_OK;
+}
+
+extern "C" int yp_kept_reset(yp_kept* k) {
+  if (!k) return fail(YP_EINVAL, "yp_kept_reset: null argument");
+  k->fresh = true;
+  return YP_OK;
+}
+
+extern "C" int yp_run_kept(yp_handle* h, yp_kept* k, int32_t batch, const float* pred_offset, const float* pred_cls,
+                           const float* pred_mask_coef, const float* priors, const float* proto, float* det_boxes,
+                           float* det_classes, float* det_scores, float* det_masks, uint8_t* det_bitmaps,
+                           int32_t* num_det, int32_t* kept_anchor_idx, void* hip_stream) {
+  if (!h || !k) return fail(YP_EINVAL, "yp_run_kept: null handle");
+  if (k->device != h->cfg.device_id || k->max_batch != h->cfg.max_batch || k->sel_rows != h->sel_rows)
+    return fail(YP_EINVAL, "yp_run_kept: this yp_kept was made for another handle's configuration");
+  if (batch < 0 || batch > h->cfg.max_batch) return fail(YP_EINVAL, "batch %d outside [0, max_batch=%d]", batch, h->cfg.max_batch);
+  if (!det_masks) return fail(YP_EINVAL, "yp_run_kept: det_masks must not be NULL (without masks there is nothing to keep track of)");
+  const int rc = check_run_args(h, pred_offset, pred_cls, pred_mask_coef, priors, proto, det_boxes, det_classes, det_scores,
+                                det_masks, det_bitmaps, num_det);
+  if (rc != YP_OK) return rc;
+  if (batch == 0) return YP_OK;
+  if (k->fresh && k->masks == nullptr) { k->masks = det_masks; k->bitmaps = det_bitmaps; k->batch = batch; }
+  if (k->masks != det_masks || k->bitmaps != det_bitmaps)
+    return fail(YP_EINVAL, "yp_run_kept: a yp_kept belongs to the mask buffers of its first call");
+  if (k->batch != batch) return fail(YP_EINVAL, "yp_run_kept: batch %d, but this yp_kept is bound to batch %d", batch, k->batch);
+  hipStream_t st = (hipStream_t)hip_stream;
+  YP_ON_DEVICE(h->cfg.device_id);
+  h->last_stream = st;
+  h->last_batch = batch;
+  const bool prof = h->profile != 0;
+  const int nw = k->side, od = nw ^ 1;
+  if (k->fresh)   // nothing is known about the buffers: the record says "no detections" and the launch below refills
+    YP_HIP(hipMemsetAsync(k->num[od], 0, (size_t)batch * sizeof(int32_t), st));
+  if (prof) YP_HIP(hipEventRecord(h->ev[0], st));
+  YP_HIP(yp_launch_score_filter(h, batch, pred_cls, pred_offset, priors, st));
+  if (prof) YP_HIP(hipEventRecord(h->ev[1], st));
+  YP_HIP(yp_launch_nms(h, batch, pred_offset, priors, det_boxes, det_classes, det_scores, num_det, kept_anchor_idx,
+                       k->fresh ? det_masks : nullptr, k->fresh ? det_bitmaps : nullptr, yp_mask_fill_rows(h), st, k->crop[nw]));
+  if (prof) YP_HIP(hipEventRecord(h->ev[2], st));
+  const yp_track trk{k->crop[nw], k->crop[od], k->num[od], k->num[nw]};
+  YP_HIP(yp_launch_mask_assemble(h, batch, proto, pred_mask_coef, num_det, det_masks, det_bitmaps, st, &trk));
+  if (prof) YP_HIP(hipEventRecord(h->ev[3], st));
+  k->side = od;
+  k->fresh = false;
+  return YP_OK;
+}
+
 // ---- the allocation-free entry point ----------------------------------------------------------------
 // Scratch of yp_run_static: one array per GPU inside the code object (every device that loads the
 // library holds its own copy, at its own address, until the process ends).  Host code never uses

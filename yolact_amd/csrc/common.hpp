@@ -255,14 +255,24 @@ hipError_t yp_launch_make_priors(int img_h, int img_w, int num_levels, const int
                                  int num_ratios, const double* sqrt_ratios, float* priors, hipStream_t st);
 hipError_t yp_launch_score_filter(const yp_handle* h, int batch, const float* pred_cls, const float* pred_offset,
                                   const float* priors, hipStream_t st);
+// A tracked output set's record for one call (yp_run_kept): the NMS launch writes the kept detections' crop edges
+// to crop_new instead of the handle's scratch; mask_assemble clears what crop_prev / num_prev say the call before
+// wrote, writes its own and leaves the count in num_new.
+struct yp_track {
+  float4* crop_new;          // [batch][sel_rows]
+  const float4* crop_prev;   // [batch][sel_rows]
+  const int32_t* num_prev;   // [batch]
+  int32_t* num_new;          // [batch]
+};
 hipError_t yp_launch_nms(const yp_handle* h, int batch, const float* pred_offset, const float* priors, float* det_boxes,
                          float* det_classes, float* det_scores, int32_t* num_det, int32_t* kept_idx,
-                         float* fill_masks, uint8_t* fill_bitmaps, int fill_rows, hipStream_t st);
+                         float* fill_masks, uint8_t* fill_bitmaps, int fill_rows, hipStream_t st, float4* crop_out = nullptr);
 int yp_mask_fill_rows(const yp_handle* h);
 hipError_t yp_launch_fill(float* masks, uint8_t* bitmaps, long long P, int fill_rows, int max_dets, int batch, hipStream_t st);
 int yp_mask_prefill(const yp_handle* h, int batch);
 hipError_t yp_launch_mask_assemble(const yp_handle* h, int batch, const float* proto, const float* pred_mask_coef,
-                                   const int32_t* num_det, float* det_masks, uint8_t* det_bitmaps, hipStream_t st);
+                                   const int32_t* num_det, float* det_masks, uint8_t* det_bitmaps, hipStream_t st,
+                                   const yp_track* track = nullptr);
 hipError_t yp_launch_mask_rle(int batch, int max_dets, int ph, int pw, const float* det_masks, const int32_t* num_det,
                               int out_h, int out_w, const int32_t* out_hw, float threshold, int order, uint8_t* bitmaps,
                               uint32_t* counts, int32_t* rle_len, int cap, hipStream_t st);

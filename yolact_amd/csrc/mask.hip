@@ -29,6 +29,10 @@ struct MaskArgs {
   uint8_t* bitmaps;        // [B,max_dets,P] or null (zeros already)
   int P, pw, ph, max_dets, sel_rows, tiles_x;
   float mask_threshold;
+  // tracked output sets (yp_run_kept; TRACK kernels only): what the call before wrote into these mask buffers
+  const float4* crop_prev;   // [B,sel_rows]
+  const int32_t* num_prev;   // [B]
+  int32_t* num_new;          // [B] this call's count, for the next call
 };
 
 #define YP_MASK_BLOCK 256
@@ -51,7 +55,10 @@ struct MaskArgs {
 //      K-ordered fma chain + sigmoid + crop and are stored over the zeros.
 // Workgroups of one image are placed on one XCD (the dispatcher deals consecutive workgroup ids
 // round-robin over the 8 XCDs), so the partial cache lines of neighbouring tiles merge in a single L2.
-template <bool NT_STORE, int NG>   // NG: 64-detection groups the kernel looks at (sel_rows <= 64 * NG)
+// TRACK (yp_run_kept): nobody zero-filled the rows.  They hold what the call before wrote - values inside ITS crop
+// boxes, zeros elsewhere - so a wave also looks at that call's crop rows and stores zeros on the pixels of those boxes
+// that this call's box of the same row does not cover.
+template <bool NT_STORE, int NG, bool TRACK>   // NG: 64-detection groups the kernel looks at (sel_rows <= 64 * NG)
 __global__ __launch_bounds__(YP_MASK_BLOCK, YP_MASK_WAVES_PER_EU) void mask_assemble_kernel(const MaskArgs p, int blocks_per_image, int batch, int by_xcd) {
   __shared__ float4 sproto[YP_MASK_BLOCK * YP_MASK_ROW4];
   typedef float nat4 __attribute__((ext_vector_type(4)));
@@ -85,6 +92,17 @@ __global__ __launch_bounds__(YP_MASK_BLOCK, YP_MASK_WAVES_PER_EU) void mask_asse
       cbv[g] = p.crop[(size_t)b * p.sel_rows + nc];
       if (p.anchor) anch[g] = p.anchor[(size_t)b * p.sel_rows + nc];
     }
+  }
+  float4 cbp[NG];    // TRACK: the same rows of the call before
+  int Np = 0;
+  if (TRACK) {
+    Np = __builtin_amdgcn_readfirstlane(min(p.num_prev[b], p.sel_rows));
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      cbp[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (g * 64 < p.sel_rows) cbp[g] = p.crop_prev[(size_t)b * p.sel_rows + min(g * 64 + lane, p.sel_rows - 1)];
+    }
+    if (tile == 0 && t == 0) p.num_new[b] = N;
   }
   nat4 x[YP_MASK_DIM / 4];
   {
@@ -122,10 +140,26 @@ __global__ __launch_bounds__(YP_MASK_BLOCK, YP_MASK_WAVES_PER_EU) void mask_asse
       }
     }
   }
+  u64 relp[NG];      // TRACK: the detections of the call before whose box can touch the quadrant
+#pragma unroll
+  for (int g = 0; g < NG; ++g) relp[g] = 0ull;
+  if (TRACK && qr0 < p.ph && qc0 < p.pw) {
+    const float fr0 = (float)qr0, fr1 = (float)min(qr0 + 7, p.ph - 1), fc0 = (float)qc0, fc1 = (float)min(qc0 + 7, p.pw - 1);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      if (g * 64 < p.sel_rows) {
+        const float4 cb = cbp[g];
+        const bool hit = (g * 64 + lane < Np) && (fc1 >= cb.x) && (fc0 < cb.y) && (fr1 >= cb.z) && (fr0 < cb.w);
+        const u64 m = __ballot(hit);
+        relp[g] = ((u64)(uint32_t)__builtin_amdgcn_readfirstlane((int)(m >> 32)) << 32) |
+                  (u64)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)m);
+      }
+    }
+  }
   // A workgroup none of whose waves is touched by any detection has nothing to write.
   u64 any_rel = 0ull;
 #pragma unroll
-  for (int g = 0; g < NG; ++g) any_rel |= rel[g];
+  for (int g = 0; g < NG; ++g) any_rel |= rel[g] | relp[g];
   if (__syncthreads_or(any_rel != 0ull) == 0) return;
 
   // The first YP_MASK_PRE detections the wave visits: their wave-uniform data - 32 coefficients and 4 crop edges
@@ -221,6 +255,31 @@ __global__ __launch_bounds__(YP_MASK_BLOCK, YP_MASK_WAVES_PER_EU) void mask_asse
       }
     }
   };
+  if (TRACK) {
+    // the pixels the call before wrote that this call's box of the same row does not cover: back to zero
+    cfloat* const cprev_c = (cfloat*)(p.crop_prev + (size_t)b * p.sel_rows);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      u64 w = relp[g];                          // wave-uniform
+      while (w != 0ull) {
+        const int n = g * 64 + __builtin_ctzll(w);
+        w &= w - 1ull;
+        float4 cp;
+        cp.x = cprev_c[4 * n + 0]; cp.y = cprev_c[4 * n + 1]; cp.z = cprev_c[4 * n + 2]; cp.w = cprev_c[4 * n + 3];
+        const bool was = live && (fcol >= cp.x) && (fcol < cp.y) && (frow >= cp.z) && (frow < cp.w);
+        bool now = false;
+        if (n < N) {                            // (wave-uniform) the row is in use again
+          float4 cn;
+          cn.x = crop_c[4 * n + 0]; cn.y = crop_c[4 * n + 1]; cn.z = crop_c[4 * n + 2]; cn.w = crop_c[4 * n + 3];
+          now = live && (fcol >= cn.x) && (fcol < cn.y) && (frow >= cn.z) && (frow < cn.w);
+        }
+        if (was && !now) {
+          orow[(size_t)n * p.P + pix] = 0.0f;
+          if (brow) brow[(size_t)n * p.P + pix] = 0;
+        }
+      }
+    }
+  }
 #pragma unroll
   for (int u = 0; u < YP_MASK_PRE; ++u)
     if (npre[u] >= 0) {
@@ -279,16 +338,18 @@ static hipError_t launch_mask_kernel(const MaskArgs& a, int batch, int ph, bool 
   // Default-policy stores: the zeros the fill has just written usually still sit (dirty) in the
   // Infinity Cache, and these stores overwrite them there.  (tune.mask_nt: non-temporal instead.)
   const int ng = (a.sel_rows + 63) / 64;
-#define YP_MASK_LAUNCH(NT, NG) hipLaunchKernelGGL((mask_assemble_kernel<NT, NG>), grid, dim3(YP_MASK_BLOCK), 0, st, a, bpi, batch, by_xcd)
-  if (nt) { if (ng <= 1) YP_MASK_LAUNCH(true, 1); else if (ng <= 2) YP_MASK_LAUNCH(true, 2); else YP_MASK_LAUNCH(true, 4); }
-  else { if (ng <= 1) YP_MASK_LAUNCH(false, 1); else if (ng <= 2) YP_MASK_LAUNCH(false, 2); else YP_MASK_LAUNCH(false, 4); }
+#define YP_MASK_LAUNCH(NT, NG, TR) hipLaunchKernelGGL((mask_assemble_kernel<NT, NG, TR>), grid, dim3(YP_MASK_BLOCK), 0, st, a, bpi, batch, by_xcd)
+  if (a.crop_prev) { if (ng <= 1) YP_MASK_LAUNCH(false, 1, true); else if (ng <= 2) YP_MASK_LAUNCH(false, 2, true); else YP_MASK_LAUNCH(false, 4, true); }
+  else if (nt) { if (ng <= 1) YP_MASK_LAUNCH(true, 1, false); else if (ng <= 2) YP_MASK_LAUNCH(true, 2, false); else YP_MASK_LAUNCH(true, 4, false); }
+  else { if (ng <= 1) YP_MASK_LAUNCH(false, 1, false); else if (ng <= 2) YP_MASK_LAUNCH(false, 2, false); else YP_MASK_LAUNCH(false, 4, false); }
 #undef YP_MASK_LAUNCH
   return hipGetLastError();
 }
 
 hipError_t yp_launch_mask_assemble(const yp_handle* h, int batch, const float* proto, const float* pred_mask_coef,
-                                   const int32_t* num_det, float* det_masks, uint8_t* det_bitmaps, hipStream_t st) {
-  if (!yp_mask_prefill(h, batch)) {   // the zeros did not ride in the NMS launch
+                                   const int32_t* num_det, float* det_masks, uint8_t* det_bitmaps, hipStream_t st,
+                                   const yp_track* track) {
+  if (!track && !yp_mask_prefill(h, batch)) {   // the zeros did not ride in the NMS launch
     const hipError_t e = yp_launch_fill(det_masks, det_bitmaps, (long long)h->cfg.proto_h * h->cfg.proto_w, yp_mask_fill_rows(h),
                                         h->cfg.max_dets, batch, st);
     if (e != hipSuccess) return e;
@@ -301,6 +362,8 @@ hipError_t yp_launch_mask_assemble(const yp_handle* h, int batch, const float* p
   a.tiles_x = (a.pw + YP_MASK_TILE - 1) / YP_MASK_TILE;
   a.max_dets = h->cfg.max_dets; a.sel_rows = h->sel_rows;
   a.mask_threshold = h->cfg.mask_threshold;
+  a.crop_prev = nullptr; a.num_prev = nullptr; a.num_new = nullptr;
+  if (track) { a.crop = track->crop_new; a.crop_prev = track->crop_prev; a.num_prev = track->num_prev; a.num_new = track->num_new; }
   return launch_mask_kernel(a, batch, a.ph, h->tune.mask_nt != 0, st);
 }
 
@@ -345,5 +408,6 @@ hipError_t yp_launch_loss_masks(int batch, int rows, int ph, int pw, int img_h, 
   a.P = ph * pw; a.pw = pw; a.ph = ph; a.tiles_x = (pw + YP_MASK_TILE - 1) / YP_MASK_TILE;
   a.max_dets = rows; a.sel_rows = rows;
   a.mask_threshold = -1.0f;
+  a.crop_prev = nullptr; a.num_prev = nullptr; a.num_new = nullptr;
   return launch_mask_kernel(a, batch, ph, false, st);
 }

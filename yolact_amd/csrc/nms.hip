@@ -1415,8 +1415,9 @@ static NmsArgs make_args(const yp_handle* h, int batch, const float* pred_offset
 // the zero-fill of rows [0, fill_rows) of every image's masks (and bitmaps) as extra workgroups.
 hipError_t yp_launch_nms(const yp_handle* h, int batch, const float* pred_offset, const float* priors, float* det_boxes,
                          float* det_classes, float* det_scores, int32_t* num_det, int32_t* kept_idx,
-                         float* fill_masks, uint8_t* fill_bitmaps, int fill_rows, hipStream_t st) {
+                         float* fill_masks, uint8_t* fill_bitmaps, int fill_rows, hipStream_t st, float4* crop_out) {
   NmsArgs a = make_args(h, batch, pred_offset, priors, det_boxes, det_classes, det_scores, num_det, kept_idx);
+  if (crop_out) a.crop = crop_out;   // a tracked output set keeps the crop edges of its last call (yp_run_kept)
   a.arrive = h->s.arrive;
   a.fill_masks = fill_masks; a.fill_bitmaps = fill_masks ? fill_bitmaps : nullptr;
   a.fill_P = (long long)h->cfg.proto_h * h->cfg.proto_w; a.fill_rows = fill_rows; a.batch = batch;

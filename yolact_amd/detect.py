@@ -95,6 +95,17 @@ class PostProcessor:
             out["detection_bitmaps"] = torch.empty((batch, c.max_dets, c.proto_h, c.proto_w), dtype=torch.uint8, device=dev)
         return out
 
+    def alloc_kept(self, batch: int, bitmaps: bool = False):
+        """An output set the library keeps track of (yp_kept_create / yp_run_kept): a dict like alloc_outputs',
+        plus the record of what the last run wrote into its masks.  `run(..., out=that dict)` then clears only the
+        previous run's crop boxes instead of refilling every row; same results.  Always pass the same dict, with the
+        same batch size, and do not write into its mask tensors yourself (``kept.reset()`` after you did)."""
+        out = KeptOutputs(self.alloc_outputs(batch, masks=True, bitmaps=bitmaps))
+        k = ctypes.c_void_p()
+        _lib.check(self._L.yp_kept_create(self._h, ctypes.byref(k)))
+        out._bind(self._L, k)
+        return out
+
     def _check(self, t: torch.Tensor, shape, name: str, dtype=torch.float32):
         if not isinstance(t, torch.Tensor) or not t.is_cuda or t.device != self.device:
             raise ValueError(f"{name} must be a CUDA tensor on {self.device}")
@@ -125,8 +136,12 @@ class PostProcessor:
         p_masks = self._check(masks, (B, md, c.proto_h, c.proto_w), "detection_masks") if masks is not None else None
         p_bits = self._check(bitmaps, (B, md, c.proto_h, c.proto_w), "detection_bitmaps", torch.uint8) if bitmaps is not None else None
         stream = torch.cuda.current_stream(self.device).cuda_stream
-        _lib.check(self._L.yp_run(self._h, B, p_off, p_cls, p_coef, p_pri, p_proto, p_boxes, p_clsout, p_scores,
-                                  p_masks, p_bits, p_num, p_aidx, ctypes.c_void_p(stream)))
+        if isinstance(out, KeptOutputs):
+            _lib.check(self._L.yp_run_kept(self._h, out._k, B, p_off, p_cls, p_coef, p_pri, p_proto, p_boxes, p_clsout,
+                                           p_scores, p_masks, p_bits, p_num, p_aidx, ctypes.c_void_p(stream)))
+        else:
+            _lib.check(self._L.yp_run(self._h, B, p_off, p_cls, p_coef, p_pri, p_proto, p_boxes, p_clsout, p_scores,
+                                      p_masks, p_bits, p_num, p_aidx, ctypes.c_void_p(stream)))
         return out
 
     def sync(self):
@@ -157,6 +172,30 @@ class PostProcessor:
         return int(self._L.yp_scratch_bytes(self._h))
 
 
+class KeptOutputs(dict):
+    """The output tensors of PostProcessor.alloc_kept together with the library's record of their masks' contents."""
+    _L = None
+    _k = None
+
+    def _bind(self, L, k):
+        self._L, self._k = L, k
+
+    def reset(self):
+        """Forget the record (after writing into the mask tensors yourself): the next run refills them."""
+        _lib.check(self._L.yp_kept_reset(self._k))
+
+    def close(self):
+        if self._k is not None and self._k.value:
+            self._L.yp_kept_destroy(self._k)
+            self._k = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def _as_device_tensor(x, device):
     if isinstance(x, torch.Tensor):
         t = x
@@ -181,10 +220,11 @@ class Detect(object):
 
     ``reuse_outputs=True`` (either mode; opt-in because it changes the lifetime of the results, not their
     values): the 300 zero-padded rows cost 23 MB of zeros per image and call, of which at most ``top_k`` rows can
-    ever hold anything else.  With this option the object keeps ONE set of output tensors per input shape, zeroed
-    when it is created, and every call rewrites only the rows a detection can land in (the kernels zero those
-    themselves); the rows behind them are never written and stay zero.  The returned tensors are then views of
-    that set and are overwritten by the next call with the same shapes - clone what must outlive it.
+    ever hold anything else - and inside those, a few per cent of the pixels.  With this option the object keeps
+    ONE set of output tensors per input shape whose contents the library tracks (``yp_run_kept``): the first call
+    zero-fills it, every later call clears exactly the crop boxes the call before wrote and writes its own.  The
+    returned tensors are that set and are overwritten by the next call with the same shapes - clone what must
+    outlive it, and do not write into the masks.
     """
 
     def __init__(self, num_classes, max_output_size, per_class_max_output_size, conf_thresh, nms_thresh, *,
@@ -257,17 +297,15 @@ class Detect(object):
                 num_anchors=A, num_classes=C, proto_h=proto_h, proto_w=proto_w, img_h=H, img_w=W,
                 conf_thresh=float(self.conf_thresh), nms_thresh=float(self.iou_thresh), nms_mode=self.nms_mode,
                 top_k=int(self.top_k), max_dets=int(self.rows), use_cropped_mask=bool(use_cropped_mask),
-                # kept outputs: the padding rows are zero already and stay so, the handle must not rewrite them
-                zero_pad_masks=self.zero_pad_masks and not self.reuse_outputs, mask_threshold=self.mask_threshold,
+                zero_pad_masks=self.zero_pad_masks, mask_threshold=self.mask_threshold,
                 max_batch=int(B), device_id=dev.index))
             self._pp[key] = pp
         with torch.cuda.device(dev):
             kept = None
             if self.reuse_outputs:
                 kept = self._outs.get((key, B))
-                if kept is None:
-                    kept = {k: torch.zeros_like(v) for k, v in
-                            pp.alloc_outputs(B, bitmaps=self.mask_threshold >= 0).items()}
+                if kept is None:          # (its first run zero-fills every row, the padding rows included)
+                    kept = pp.alloc_kept(B, bitmaps=self.mask_threshold >= 0)
                     self._outs[(key, B)] = kept
             out = pp.run(box_p, class_p, coef_p, anchors, proto_p, out=kept)
         result = {'detection_boxes': out['detection_boxes'], 'detection_classes': out['detection_classes'],
