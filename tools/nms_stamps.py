@@ -1,5 +1,6 @@
 """Diagnostic (needs a library built with -DYP_STAMPS): per-phase cycle counts of the NMS kernels.
-usage: python -m yolact_amd.build -DYP_STAMPS && python tools/nms_stamps.py [per_class|cc] [config]"""
+usage: python -m yolact_amd.build -DYP_STAMPS && python tools/nms_stamps.py [per_class|cc] [config] [kept]
+(kept: library-tracked output sets, i.e. no zero-fill workgroups beside the NMS)"""
 import ctypes, sys, os
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -12,7 +13,8 @@ ph, pw = net["proto_out"].shape[1:3]
 pp = PostProcessor(PostConfig(A, C, ph, pw, cfg.img_h, cfg.img_w, conf_thresh=cfg.conf_thresh, nms_mode=mode, top_k=cfg.top_k,
                               max_dets=cfg.max_dets, max_batch=B))
 d = {k: torch.from_numpy(v).cuda() for k, v in net.items()}
-outs = [pp.alloc_outputs(B) for _ in range(3)]     # rotating output sets, as bench.py's headline does
+kept = len(sys.argv) > 3 and sys.argv[3] == "kept"
+outs = [pp.alloc_kept(B) if kept else pp.alloc_outputs(B) for _ in range(3)]     # rotating output sets, as bench.py's headline does
 for i in range(9):
     pp.run(d["pred_offset"], d["pred_cls"], d["pred_mask_coef"], d["priors"], d["proto_out"], out=outs[i % 3])
 pp.sync()
