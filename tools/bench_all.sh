@@ -9,3 +9,6 @@ run c3 --config 3
 run c5 --config 5
 run c1cc --config 1 --nms-mode cc
 run c2cov --box-coverage 0.13
+run c2kept --kept-outputs
+run c2ref --reference-layout
+run c2refkept --reference-layout --kept-outputs

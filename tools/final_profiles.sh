@@ -6,6 +6,7 @@ bash tools/gpu_profile.sh r03_cc cc > /dev/null
 bash tools/gpu_profile.sh r03_c4 per_class --config 4 > /dev/null
 bash tools/gpu_profile.sh r03_c1 cc --config 1 > /dev/null
 bash tools/gpu_profile.sh r03_cov per_class --box-coverage 0.13 > /dev/null
+bash tools/gpu_profile.sh r03_kept per_class --kept-outputs > /dev/null
 bash tools/bench_all.sh
 timeout -k 10 120 python3 tools/bench_consumer.py > gpurun_out/ball/consumer.json 2> gpurun_out/ball/consumer.err
 timeout -k 10 600 python3 bench.py > gpurun_out/ball/default.json 2> gpurun_out/ball/default.err
