@@ -455,6 +455,72 @@ __device__ __forceinline__ int select_topk_sorted(const Src& src, int n, int wan
   return k;
 }
 
+// Selection from REGISTERS with fixed score bins - the fast form of select_topk_sorted for a workgroup whose threads
+// already hold every key (at most NK each).  The general selection first finds the bit range in which the keys differ
+// (a pass and a barrier), stages or re-reads the keys for its histogram, takes the k-th bin and above, rank-sorts and
+// leaves it to the caller to find where its own keys went (a binary search per key).  Here the bins are fixed in
+// advance: the score bits above the confidence threshold, cut to YP_RADIX_BITS bits (NmsArgs::sel_base / sel_shift) -
+// monotone in the key, which is all a selection needs.  The keys go from the registers straight into the histogram;
+// the keys of the k-th bin and above are appended to sh.tmp, rank-sorted into sh.key, and every owner is told the
+// rank of each of its keys, so that it can drop the key's payload (box, output row) at its place from its own
+// registers.  Six barriers.
+//   in:  sh.hist[0..YP_RADIX_BINS) == 0, sh.rank[0..YP_SORT_MAX) == 0, sh.fill == 0, published by a barrier
+//   out: the return value m >= k: sh.key[0..m) holds the m largest keys, descending (the first k are the answer);
+//        rank[u] = position of key[u] in it, or -1.  sh.rank is zero again.
+//        -1 (workgroup-uniform) if the bins do not isolate <= YP_SORT_MAX keys around the k-th (a score plateau):
+//        nothing has been selected and the caller takes the general path.
+// All threads must call it; k >= 1 and at most the number of valid keys.
+template <int THREADS, int NK>
+__device__ __forceinline__ int select_from_registers(const u64 (&key)[NK], const bool (&valid)[NK], int k, uint32_t sel_base,
+                                                     int sel_shift, SelectShared& sh, int (&rank)[NK]) {
+  const int t = threadIdx.x;
+  int bin[NK];
+#pragma unroll
+  for (int u = 0; u < NK; ++u) {
+    const uint32_t sb = (uint32_t)(key[u] >> 32);
+    bin[u] = valid[u] ? (int)min((sb > sel_base ? sb - sel_base : 0u) >> sel_shift, (uint32_t)(YP_RADIX_BINS - 1)) : -1;
+    if (bin[u] >= 0) atomicAdd(&sh.hist[bin[u]], 1);
+    rank[u] = -1;
+  }
+  __syncthreads();
+  hist_locate<THREADS>(k, sh);
+  const int sel = sh.sel;
+  const int m = (k - sh.need) + sh.cnt;                       // keys in bins >= sel
+  if (m > YP_SORT_MAX) return -1;
+  int slot[NK];
+#pragma unroll
+  for (int u = 0; u < NK; ++u) {
+    slot[u] = -1;
+    if (bin[u] >= sel) {
+      slot[u] = lds_append_slot(&sh.fill);
+      sh.tmp[slot[u]] = key[u];
+    }
+  }
+  __syncthreads();
+  constexpr int G = THREADS / YP_SORT_MAX >= 1 ? THREADS / YP_SORT_MAX : 1;
+  const int j = t % YP_SORT_MAX, g = t / YP_SORT_MAX;
+  u64 mine = 0;
+  if (j < m && g < G) {
+    mine = sh.tmp[j];
+    int c = 0;
+#pragma unroll 8
+    for (int i = g; i < m; i += G) c += sh.tmp[i] > mine ? 1 : 0;
+    if (c) atomicAdd(&sh.rank[j], c);
+  }
+  __syncthreads();
+  if (t < m) {
+    const int r = sh.rank[t];
+    sh.key[r] = mine;
+    sh.tmp[t] = (u64)r;                                       // slot -> rank, for the key's owner
+    sh.rank[t] = 0;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < NK; ++u)
+    if (slot[u] >= 0) rank[u] = (int)sh.tmp[slot[u]];
+  return m;
+}
+
 // iou(a, b) > thr with utils._iou's arithmetic (utils/utils.py:19-21, 40-48, 63-70), without the
 // division wherever the answer cannot depend on its rounding: thr*union is within 2^-24 of exact, so
 // an intersection outside thr*union*(1 -+ 2^-21) is on one side of the threshold for any correctly
@@ -792,56 +858,23 @@ __global__ __launch_bounds__(THREADS) void cc_nms_kernel(const NmsArgs p) {
   const int k = min(p.top_k, n);
   // ---- selection from registers (the usual case: no list is longer than the first batch) ----------------------
   // Small batches are latency: the general selection below costs ten barriers (min/max pass, histogram, take,
-  // rank sort, box placement).  Here the bins are fixed in advance - the score bits above the confidence
-  // threshold, cut to 11 bits: monotone in the key, which is all the selection needs - so the keys go from the
-  // registers straight into the histogram, the keys of the k-th bin and above are taken TOGETHER WITH their boxes,
-  // and the rank sort drops both at their place: six barriers.  The result is the same k keys in the same order
+  // rank sort, box placement); select_from_registers six.  The result is the same k keys in the same order
   // (unique keys); if the fixed bins do not isolate <= 256 keys the general path runs instead.
   bool in_regs = true;
 #pragma unroll
   for (int i = 0; i < YP_NLISTS; ++i) in_regs = in_regs && s_cnt[i] <= YP_CC_PRE * YP_WAVE;
   int m = -1;
   if (in_regs) {                                                // (workgroup-uniform)
-    float4* const tbox = reinterpret_cast<float4*>(stage);     // idle here: only the general path stages keys
     const int nl = s_cnt[l];
-    int bin[YP_CC_PRE];
+    bool valid[YP_CC_PRE];
+    int rk[YP_CC_PRE];
 #pragma unroll
-    for (int u = 0; u < YP_CC_PRE; ++u) {
-      const uint32_t sb = (uint32_t)(src.pre[u] >> 32);
-      bin[u] = q + u * YP_WAVE < nl ? (int)min((sb > p.sel_base ? sb - p.sel_base : 0u) >> p.sel_shift, (uint32_t)(YP_RADIX_BINS - 1)) : -1;
-      if (bin[u] >= 0) atomicAdd(&s_hist[bin[u]], 1);
-    }
-    __syncthreads();
-    hist_locate<THREADS>(k, sh);
-    const int sel = sh.sel;
-    const int superset = (k - sh.need) + sh.cnt;                // keys in bins >= sel
-    if (superset <= YP_SORT_MAX) {
+    for (int u = 0; u < YP_CC_PRE; ++u) valid[u] = q + u * YP_WAVE < nl;
+    m = select_from_registers<THREADS, YP_CC_PRE>(src.pre, valid, k, p.sel_base, p.sel_shift, sh, rk);
+    if (m >= 0) {
 #pragma unroll
       for (int u = 0; u < YP_CC_PRE; ++u)
-        if (bin[u] >= sel) {
-          const int slot = lds_append_slot(&sh.fill);
-          sh.tmp[slot] = src.pre[u];
-          tbox[slot] = preb[u];
-        }
-      __syncthreads();
-      constexpr int G = THREADS / YP_SORT_MAX;
-      const int j = t % YP_SORT_MAX, g = t / YP_SORT_MAX;
-      u64 mine = 0;
-      if (j < superset) {
-        mine = sh.tmp[j];
-        int c = 0;
-#pragma unroll 8
-        for (int i = g; i < superset; i += G) c += sh.tmp[i] > mine ? 1 : 0;
-        if (c) atomicAdd(&sh.rank[j], c);
-      }
-      __syncthreads();
-      if (t < superset) {
-        const int r = sh.rank[t];
-        sh.key[r] = mine;
-        sbox[r] = tbox[t];
-        sh.rank[t] = 0;
-      }
-      m = superset;
+        if (rk[u] >= 0 && rk[u] < k) sbox[rk[u]] = preb[u];    // detection.py:187: the selected keys' boxes, by their owners
     }
     __syncthreads();
   }
