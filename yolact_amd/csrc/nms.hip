@@ -470,6 +470,13 @@ __device__ __forceinline__ int select_topk_sorted(const Src& src, int n, int wan
 //        -1 (workgroup-uniform) if the bins do not isolate <= YP_SORT_MAX keys around the k-th (a score plateau):
 //        nothing has been selected and the caller takes the general path.
 // All threads must call it; k >= 1 and at most the number of valid keys.
+// (Tried in the per-class kernel as well - the cut of a group's pool to its best max_dets and the image's final
+//  selection, both of which hold their keys in registers: 30.0 -> 28.4 us for the chain on tracked output sets (no
+//  fill beside it), nothing measurable under the fill, and +2-4 us at config 4, whose pools are a thousand EQUAL
+//  scores just below 1.0 ordered by anchor alone - every key in one bin, a thousand LDS atomics on one address - and
+//  whose group kernel, already spilling at its 80-register bound, spilled more with the extra code even when the
+//  attempt was skipped.  Two-scale bins (linear above 0.5) and a second histogram level did not change that.  Left
+//  out there.)
 template <int THREADS, int NK>
 __device__ __forceinline__ int select_from_registers(const u64 (&key)[NK], const bool (&valid)[NK], int k, uint32_t sel_base,
                                                      int sel_shift, SelectShared& sh, int (&rank)[NK]) {
