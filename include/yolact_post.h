@@ -132,7 +132,9 @@ int yp_run(yp_handle* h, int32_t batch,
  *                    to these det_masks / det_bitmaps pointers and to this batch size; later calls must pass the same
  *                    pointers and batch (YP_EINVAL otherwise) and must not be overlapped with each other.  Nobody else
  *                    may write the mask buffers in between.  det_masks must not be NULL.
- *   yp_kept_reset    forget the record: the next call refills (after the caller wrote into the buffers itself) */
+ *   yp_kept_reset    forget the record: the next call refills (after the caller wrote into the buffers itself)
+ * The record's two slots swap on the HOST at every call: a yp_run_kept captured in a HIP graph would replay one
+ * side for ever - capture yp_run / yp_run_static instead.  yp_kept_create allocates (hipMalloc); yp_run_kept does not. */
 typedef struct yp_kept yp_kept;
 int yp_kept_create(yp_handle* h, yp_kept** out);
 int yp_kept_destroy(yp_kept* k);
