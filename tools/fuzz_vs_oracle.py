@@ -34,13 +34,32 @@ for i in range(cases):
     pp.sync()
     got = to_numpy(out)
     got["num_survivors"] = pp.last_survivors(B)
-    pp.close()
-    ref = c_oracle.detect(net, shp, conf_thresh=conf, nms_thresh=nms, top_k=top_k, nms_mode=mode, max_dets=max_dets, use_cropped_mask=crop, nthreads=8)
+    kw = dict(conf_thresh=conf, nms_thresh=nms, top_k=top_k, nms_mode=mode, max_dets=max_dets, use_cropped_mask=crop, nthreads=8)
+    ref = c_oracle.detect(net, shp, **kw)
     try:
         assert np.array_equal(got["num_survivors"], ref["num_survivors"]), "num_survivors"
         compare(got, ref, exact_values=True, label=f"case{i}")
+        # the same handle on a tracked output set (yp_run_kept): this batch, another one of the same shape, this one
+        # again - every run must equal the oracle although nothing refills the masks after the first
+        net2, _ = synth.make_toy(int(rng.integers(0, 10**6)), batch=B, fmaps=((f0, f0), (f1, f1)), num_classes=C, proto_hw=proto,
+                                 p_fg=float(rng.choice([0.02, 0.5, 0.95])))
+        dev2 = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in net2.items()}
+        ref2 = c_oracle.detect(net2, shp, **kw)
+        kept = pp.alloc_kept(B)
+        for v in kept.values():
+            v.fill_(3)
+        for d, r, tag in ((dev, ref, "a"), (dev2, ref2, "b"), (dev, ref, "a2")):
+            pp.run(d["pred_offset"], d["pred_cls"], d["pred_mask_coef"], d["priors"], d["proto_out"], out=kept)
+            pp.sync()
+            gk = to_numpy(kept)
+            compare(gk, r, exact_values=True, label=f"case{i}/kept-{tag}")
+            lim = min(max_dets, 256) if mode == "per_class" else min(max_dets, top_k, 256)
+            for b in range(B):                      # the rows behind the detections, as far as a detection can land
+                assert not gk["detection_masks"][b, int(r["num_detections"][b]):lim].any(), f"case{i}/kept-{tag}: stale mask rows, image {b}"
+        kept.close()
     except AssertionError as e:
         bad += 1
         print(f"MISMATCH case {i}: C={C} A={A} B={B} conf={conf} nms={nms} mode={mode} top_k={top_k} max_dets={max_dets} crop={crop} p_fg={p_fg}: {str(e)[:200]}")
+    pp.close()
 print(f"{cases} cases, {bad} mismatches")
 sys.exit(1 if bad else 0)
