@@ -345,3 +345,26 @@ def test_loss_mask_assembly_autograd():
     ((ref - target) ** 2 * inside + (1 - inside) * target ** 2).sum().backward()
     assert torch.allclose(gp, proto.grad, rtol=1e-4, atol=1e-4) and torch.allclose(gc, coef.grad, rtol=1e-4, atol=1e-3)
     assert not gc[2].any() and not gc[1, 4:].any()
+
+
+def test_sharded_detect_returns_rle_instead_of_float_masks():
+    """ShardedDetect(..., rle_hw=...): every shard resizes, thresholds and run-length encodes its masks on its own GPU
+    and only the strings travel (two shards on the one GPU here).  Equal to the unsharded consumer chain, image by
+    image, with every image at its own size."""
+    from yolact_amd import Detect, consumer, synth
+    from yolact_amd.sharding import ShardedDetect
+    import torch
+    cfg = synth.CONFIGS[2]
+    net, shp = synth.make_batch(cfg, batch=5)
+    dev = {k: torch.from_numpy(v).cuda() for k, v in net.items()}
+    sizes = [(480, 640), (550, 550), (333, 500), (640, 427), (600, 600)]
+    args = (cfg.num_classes, 300, 100, cfg.conf_thresh, 0.5)
+    kw = dict(strict_reference=False, nms_mode="per_class", top_k=200, max_dets=100)
+    whole = Detect(*args, **kw)(dev, shp)
+    want = consumer.rle_dicts(consumer.masks_to_rle(whole["detection_masks"], whole["num_detections"], sizes))
+    sd = ShardedDetect(*args, devices=[0, 0], **kw)
+    got = sd(dev, shp, rle_hw=sizes)
+    assert "detection_masks" not in got and len(got["detection_rle"]) == 5
+    assert got["detection_rle"] == want
+    assert torch.equal(got["num_detections"], whole["num_detections"].cpu())
+    assert all(t["rle_ms"] is not None and t["images"] in (2, 3) for t in sd.last_timing)

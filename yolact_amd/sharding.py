@@ -96,10 +96,24 @@ class ShardedDetect:
                 self._host[sig] = buf
             return buf
 
-    def __call__(self, net_outs, img_shape, trad_nms=False, use_cropped_mask=True):
+    def __call__(self, net_outs, img_shape, trad_nms=False, use_cropped_mask=True, rle_hw=None, rle_threshold=0.5,
+                 rle_order="resize_then_threshold"):
+        """``rle_hw`` - one (height, width) or one per image: what the evaluation loop does with the masks
+        (coco_eval.py:131-137: resize to the image's own size, ``> 0.5``, ``mask.encode``) runs on every shard's GPU
+        and the float masks stay there.  The result then has ``detection_rle`` - per image the list of
+        ``{'size': [h, w], 'counts': str}`` of its detections, image order - instead of ``detection_masks``:
+        kilobytes per image over PCIe instead of ``max_dets x ph x pw x 4`` bytes (config 3: 19.7 MB per image,
+        22 ms for a batch of 64 over one link against a 0.57 ms compute step)."""
+        import time
         import torch
+        from . import consumer
         B = int(net_outs["pred_cls"].shape[0])
         G = len(self.devices)
+        if rle_hw is not None:
+            per_image = len(rle_hw) > 0 and hasattr(rle_hw[0], "__len__")
+            sizes = [tuple(int(v) for v in hw) for hw in rle_hw] if per_image else [(int(rle_hw[0]), int(rle_hw[1]))] * B
+            if len(sizes) != B:
+                raise ValueError("rle_hw must be one (height, width) or one per image")
 
         def work(r):
             lo, hi = shard_bounds(B, G, r)
@@ -111,15 +125,25 @@ class ShardedDetect:
                 e0.record(st)
                 res = self.detects[r](slice_net_outs(net_outs, lo, hi), img_shape, trad_nms, use_cropped_mask)
                 e1.record(st)
+                enc, rle_ms = None, None
+                if rle_hw is not None:                                  # the consumers' step, on this shard's GPU
+                    t0 = time.perf_counter()
+                    enc = consumer.rle_dicts(consumer.masks_to_rle(res["detection_masks"], res["num_detections"],
+                                                                   sizes[lo:hi], threshold=rle_threshold, order=rle_order))
+                    rle_ms = (time.perf_counter() - t0) * 1e3
+                e1b = torch.cuda.Event(enable_timing=True)
+                e1b.record(st)
                 views = {}
                 for k, v in res.items():
+                    if rle_hw is not None and k in ("detection_masks", "detection_bitmaps"):
+                        continue                                        # the float masks stay on the device
                     buf = self._host_buffer(B, k, v)
                     buf[lo:hi].copy_(v, non_blocking=True)
                     views[k] = buf
                 e2.record(st)
                 st.synchronize()                                       # the shard's one synchronisation
                 return views, {"device": self.devices[r], "images": hi - lo, "compute_ms": e0.elapsed_time(e1),
-                               "gather_ms": e1.elapsed_time(e2)}
+                               "gather_ms": e1b.elapsed_time(e2), "rle_ms": rle_ms}, (lo, enc)
 
         futures = [self._pool.submit(work, r) for r in range(G)]      # every shard is in flight before any is awaited
         done = [f.result() for f in futures]
@@ -127,4 +151,7 @@ class ShardedDetect:
         if not done:
             raise ValueError("no results")
         self.last_timing = [d[1] for d in done]
-        return dict(done[0][0])                                         # whole-batch buffers, image order
+        out = dict(done[0][0])                                          # whole-batch buffers, image order
+        if rle_hw is not None:
+            out["detection_rle"] = [e for _, enc in sorted((d[2] for d in done), key=lambda x: x[0]) for e in enc]
+        return out
