@@ -146,3 +146,30 @@ def test_batched_rle_strings_match_the_oracle_and_the_single_call():
     flat = np.concatenate([counts[i, :lens[i]] for i in range(n)])
     pst = np.concatenate([[0], np.cumsum(lens[:-1])]).astype(np.int64)
     assert consumer.rle_strings(flat, lens, pst) == got
+
+
+def test_batched_rle_strings_on_several_threads():
+    """A batch's worth of lists (more than 65536 counts) is encoded by several host threads: the strings, their
+    offsets and the truncation of a buffer that is too small are those of the one-list call."""
+    import ctypes
+    from yolact_amd import _lib, consumer
+    rng = np.random.default_rng(11)
+    n = 700
+    lens = rng.integers(0, 400, n).astype(np.int32); lens[::50] = 0; lens[13] = 5000        # ragged, one long list
+    starts = np.concatenate([[0], np.cumsum(lens[:-1])]).astype(np.int64)
+    flat = rng.integers(0, 90000, int(lens.sum())).astype(np.uint32)
+    assert flat.size > 65536
+    got = consumer.rle_strings(flat, lens, starts)
+    for i in range(0, n, 7):
+        assert got[i] == consumer.rle_string(flat[starts[i]:starts[i] + lens[i]]), i
+    assert got[13] == consumer.rle_string(flat[starts[13]:starts[13] + 5000])
+    L = _lib.load()
+    need = sum(len(x) + 1 for x in got)
+    cap = need // 2
+    buf = ctypes.create_string_buffer(cap); offs = np.zeros(n + 1, np.int64)
+    assert L.yp_rle_strings(flat.ctypes.data, starts.ctypes.data, lens.ctypes.data, n, flat.size, ctypes.addressof(buf), cap, offs.ctypes.data) == need
+    raw = buf.raw
+    whole = [i for i in range(n) if offs[i + 1] <= cap]          # the strings that fit are complete, in their places
+    assert len(whole) > 100
+    for i in whole:
+        assert raw[offs[i]:offs[i + 1] - 1].decode("ascii") == got[i]

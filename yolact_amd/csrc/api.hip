@@ -7,6 +7,8 @@
 #include <string.h>
 
 #include <mutex>
+#include <thread>
+#include <vector>
 #include <new>
 
 #include "common.hpp"
@@ -685,18 +687,49 @@ extern "C" int64_t yp_rle_strings(const uint32_t* counts, const int64_t* starts,
                                   int64_t n_counts, char* out, int64_t out_cap, int64_t* offsets) {
   if (!counts || !starts || !lens || !out || !offsets || n_lists < 0 || n_counts < 0 || out_cap < 1)
     return fail(YP_EINVAL, "yp_rle_strings: bad argument");
-  int64_t pos = 0;
+  int64_t total = 0;
   for (int i = 0; i < n_lists; ++i) {
     if (lens[i] < 0 || starts[i] < 0 || starts[i] + lens[i] > n_counts)
       return fail(YP_EINVAL, "yp_rle_strings: list %d (start %lld, %d counts) leaves the array of %lld counts", i, (long long)starts[i], lens[i],
                   (long long)n_counts);
-    offsets[i] = pos;
-    const int64_t room = out_cap - pos;   // (<= 0 once the buffer is full: nothing more is written, the lengths still add up)
-    const long long len = rle_encode(counts + starts[i], lens[i], room > 0 ? out + pos : out, room > 0 ? room : 1);
-    if (room > 0) out[pos + (len < room - 1 ? len : room - 1)] = 0;
-    pos += len + 1;
+    total += lens[i];
   }
+  // A batch's worth of lists (config 2: 3200 lists, 0.9 M counts, 5 ms on one core) is cut into runs of lists with
+  // about equal numbers of counts, one host thread each: first every string's length, then - the offsets known -
+  // the strings themselves.  Same bytes as the one-thread loop, truncation of a full buffer included.
+  unsigned hw = std::thread::hardware_concurrency();
+  int nthreads = (int)(hw == 0 ? 1 : (hw > 8 ? 8 : hw));
+  if (total < 65536 || n_lists < 2 * nthreads) nthreads = 1;
+  std::vector<int> cut(nthreads + 1, n_lists);
+  cut[0] = 0;
+  {
+    int64_t acc = 0;
+    int k = 1;
+    for (int i = 0; i < n_lists && k < nthreads; ++i) {
+      acc += lens[i];
+      if (acc * nthreads >= total * k) cut[k++] = i + 1;
+    }
+  }
+  std::vector<long long> slen((size_t)n_lists);
+  auto run = [&](auto&& body) {
+    if (nthreads == 1) { body(0, n_lists); return; }
+    std::vector<std::thread> th;
+    for (int k = 0; k < nthreads; ++k) th.emplace_back(body, cut[k], cut[k + 1]);
+    for (auto& t : th) t.join();
+  };
+  char dummy;
+  run([&](int lo, int hi) { for (int i = lo; i < hi; ++i) slen[i] = rle_encode(counts + starts[i], lens[i], &dummy, 1); });
+  int64_t pos = 0;
+  for (int i = 0; i < n_lists; ++i) { offsets[i] = pos; pos += slen[i] + 1; }
   offsets[n_lists] = pos;
+  run([&](int lo, int hi) {
+    for (int i = lo; i < hi; ++i) {
+      const int64_t room = out_cap - offsets[i];   // (<= 0 once the buffer is full: nothing more is written)
+      if (room <= 0) continue;
+      const long long len = rle_encode(counts + starts[i], lens[i], out + offsets[i], room);
+      out[offsets[i] + (len < room - 1 ? len : room - 1)] = 0;
+    }
+  });
   return pos;
 }
 
