@@ -19,6 +19,9 @@ ORDERS = {"resize_then_threshold": _lib.YP_RESIZE_THEN_THRESHOLD,     # coco_eva
           "threshold_then_resize": _lib.YP_THRESHOLD_THEN_RESIZE}     # train.py:497,504-505
 
 
+_CAP_HINT = {}     # (max_dets, ph, pw, widest output) -> run-list capacity that the last overflowing call needed
+
+
 def masks_to_rle(det_masks: torch.Tensor, num_det: torch.Tensor, out_hw, threshold: float = 0.5,
                  order: str = "resize_then_threshold", bitmaps: bool = False, rle_cap: int | None = None):
     """Resize + binarise + run-length encode the first ``num_det[b]`` masks of every image.
@@ -52,7 +55,10 @@ def masks_to_rle(det_masks: torch.Tensor, num_det: torch.Tensor, out_hw, thresho
     else:
         out_h, out_w = int(out_hw[0]), int(out_hw[1])
         full, widest, size_out = out_h * out_w + 1, out_w, (out_h, out_w)
-    cap = min(full, int(rle_cap) if rle_cap is not None else 8 * widest + 64)
+    # (without an explicit rle_cap: start from what the last call with masks and outputs of this shape needed, so that a
+    #  loop over batches repeats the encoding at most once)
+    hint_key = (md, ph, pw, widest)
+    cap = min(full, int(rle_cap) if rle_cap is not None else max(8 * widest + 64, _CAP_HINT.get(hint_key, 0)))
     bm = torch.empty((B, md, out_h, out_w), dtype=torch.uint8, device=dev) if bitmaps else None
     while True:
         counts = torch.empty((B, md, cap), dtype=torch.int32, device=dev)
@@ -69,7 +75,9 @@ def masks_to_rle(det_masks: torch.Tensor, num_det: torch.Tensor, out_hw, thresho
         need = int(lens.max().item()) if B * md > 0 else 0
         if need <= cap:
             return {"counts": counts, "len": lens, "bitmaps": bm, "size": size_out}
-        cap = min(full, need)
+        cap = min(full, need + need // 4)                    # some room for the next batch's longest list
+        if cap <= 8 * (8 * widest + 64) and B * md * cap * 4 <= (1 << 30):   # (one noise mask must not size every later call)
+            _CAP_HINT[hint_key] = cap
 
 
 def rle_string(counts: np.ndarray) -> str:
