@@ -193,7 +193,11 @@ def test_cross_workgroup_handoff_is_write_through_in_the_emitted_isa():
     on the consumer's side.  The C++ memory model promises nothing for relaxed stores without a release, so what
     the compiler emits is pinned here: a toolchain that lowers it differently fails the build
     check instead of corrupting detections now and then."""
-    isa = _disassemble_kernel("group_nms_kernel")
+    for inst in ("group_nms_kernelILi512ELi6E", "group_nms_kernelILi512ELi4E"):   # beside a fill / launched alone
+        _check_handoff_isa(_disassemble_kernel(inst))
+
+
+def _check_handoff_isa(isa):
     wt8 = [l for l in isa if l.startswith("global_store_dwordx2") and " sc1" in l]
     wt4 = [l for l in isa if l.startswith("global_store_dword ") and " sc1" in l]
     assert len(wt8) >= 4, "the pool's keys and boxes (8-byte halves) must be stored with sc1 (write-through)"

@@ -1361,8 +1361,13 @@ __device__ __forceinline__ void final_select_body(const NmsArgs& p, int b, Group
 #define YP_GROUP_MIN_WAVES 6   // waves per SIMD the register allocation must allow: 6 = three 512-thread workgroups per CU
                                // (two NMS + one fill; measured per launch at config 2: 66 us at 4, 60 at 6, 61 at 8)
 #endif
-template <int THREADS>
-__global__ __launch_bounds__(THREADS, YP_GROUP_MIN_WAVES) void group_nms_kernel(const NmsArgs p) {
+#ifndef YP_GROUP_MIN_WAVES_ALONE
+#define YP_GROUP_MIN_WAVES_ALONE 4   // ... of the instantiation that is launched without fill workgroups (tracked output sets):
+                                     // nothing has to fit beside the NMS workgroups then, and at 128 registers the kernel does
+                                     // not spill (28.6 us against 30.3 per launch; under a fill it is 63.7 against 52.9)
+#endif
+template <int THREADS, int MIN_WAVES>
+__global__ __launch_bounds__(THREADS, MIN_WAVES) void group_nms_kernel(const NmsArgs p) {
   if ((int)blockIdx.x >= p.nms_blocks) {   // workgroup-uniform
     fill_loop<THREADS>(p, (int)blockIdx.x - p.nms_blocks);
     return;
@@ -1477,7 +1482,8 @@ hipError_t yp_launch_nms(const yp_handle* h, int batch, const float* pred_offset
     if (a.fill_masks) nfill += fill_chunks_per_image<T>(a.fill_P, fill_rows, 4) * batch;
     if (a.fill_bitmaps) nfill += fill_chunks_per_image<T>(a.fill_P, fill_rows, 1) * batch;
     a.fill_first = 0; a.fill_last = nfill; a.fill_wgs = (int)(nfill < max_wgs ? nfill : max_wgs);
-    hipLaunchKernelGGL((group_nms_kernel<T>), dim3((unsigned)(a.nms_blocks + a.fill_wgs)), dim3(T), 0, st, a);
+    if (a.fill_wgs > 0) hipLaunchKernelGGL((group_nms_kernel<T, YP_GROUP_MIN_WAVES>), dim3((unsigned)(a.nms_blocks + a.fill_wgs)), dim3(T), 0, st, a);
+    else hipLaunchKernelGGL((group_nms_kernel<T, YP_GROUP_MIN_WAVES_ALONE>), dim3((unsigned)a.nms_blocks), dim3(T), 0, st, a);
   }
   return hipGetLastError();
 }
