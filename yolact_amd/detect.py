@@ -221,7 +221,7 @@ class Detect(object):
     ``reuse_outputs=True`` (either mode; opt-in because it changes the lifetime of the results, not their
     values): the 300 zero-padded rows cost 23 MB of zeros per image and call, of which at most ``top_k`` rows can
     ever hold anything else - and inside those, a few per cent of the pixels.  With this option the object keeps
-    ONE set of output tensors per input shape whose contents the library tracks (``yp_run_kept``): the first call
+    ONE set of output tensors per input shape (the last four shapes) whose contents the library tracks (``yp_run_kept``): the first call
     zero-fills it, every later call clears exactly the crop boxes the call before wrote and writes its own.  The
     returned tensors are that set and are overwritten by the next call with the same shapes - clone what must
     outlive it, and do not write into the masks.
@@ -305,6 +305,8 @@ class Detect(object):
             if self.reuse_outputs:
                 kept = self._outs.get((key, B))
                 if kept is None:          # (its first run zero-fills every row, the padding rows included)
+                    while len(self._outs) >= 4:                         # a set is a whole batch of masks: keep a few
+                        self._outs.pop(next(iter(self._outs))).close()
                     kept = pp.alloc_kept(B, bitmaps=self.mask_threshold >= 0)
                     self._outs[(key, B)] = kept
             out = pp.run(box_p, class_p, coef_p, anchors, proto_p, out=kept)
