@@ -714,8 +714,13 @@ extern "C" int64_t yp_rle_strings(const uint32_t* counts, const int64_t* starts,
   auto run = [&](auto&& body) {
     if (nthreads == 1) { body(0, n_lists); return; }
     std::vector<std::thread> th;
-    for (int k = 0; k < nthreads; ++k) th.emplace_back(body, cut[k], cut[k + 1]);
+    int started = 0;
+    try {                                       // (no exception may leave a C entry point)
+      for (; started < nthreads; ++started) th.emplace_back(body, cut[started], cut[started + 1]);
+    } catch (...) {
+    }
     for (auto& t : th) t.join();
+    if (started < nthreads) body(cut[started], n_lists);   // the runs no thread could be started for: here
   };
   char dummy;
   run([&](int lo, int hi) { for (int i = lo; i < hi; ++i) slen[i] = rle_encode(counts + starts[i], lens[i], &dummy, 1); });
