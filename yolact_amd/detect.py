@@ -93,7 +93,7 @@ class PostProcessor:
             out["detection_masks"] = torch.empty((batch, c.max_dets, c.proto_h, c.proto_w), dtype=torch.float32, device=dev)
         if bitmaps:
             out["detection_bitmaps"] = torch.empty((batch, c.max_dets, c.proto_h, c.proto_w), dtype=torch.uint8, device=dev)
-        return out
+        return OutputSet(out)
 
     def alloc_kept(self, batch: int, bitmaps: bool = False):
         """An output set the library keeps track of (yp_kept_create / yp_run_kept): a dict like alloc_outputs',
@@ -116,7 +116,8 @@ class PostProcessor:
     def run(self, pred_offset, pred_cls, pred_mask_coef, priors, proto, out=None):
         c = self.cfg
         B = int(pred_cls.shape[0])
-        if out is None:
+        fresh = out is None
+        if fresh:
             out = self.alloc_outputs(B, masks=proto is not None, bitmaps=c.mask_threshold >= 0 and proto is not None)
         A, C, K = c.num_anchors, c.num_classes, c.mask_dim
         p_off = self._check(pred_offset, (B, A, 4), "pred_offset")
@@ -125,16 +126,24 @@ class PostProcessor:
         p_pri = self._check(priors, (A, 4), "priors")
         md = c.max_dets
         masks = out.get("detection_masks")
-        bitmaps = out.get("detection_bitmaps")
         p_proto = self._check(proto, (B, c.proto_h, c.proto_w, K), "proto_out") if masks is not None else None
-        p_boxes = self._check(out["detection_boxes"], (B, md, 4), "detection_boxes")
-        p_clsout = self._check(out["detection_classes"], (B, md), "detection_classes")
-        p_scores = self._check(out["detection_scores"], (B, md), "detection_scores")
-        p_num = self._check(out["num_detections"], (B,), "num_detections", torch.int32)
-        aidx = out.get("detection_anchor_indices")
-        p_aidx = self._check(aidx, (B, md), "detection_anchor_indices", torch.int32) if aidx is not None else None
-        p_masks = self._check(masks, (B, md, c.proto_h, c.proto_w), "detection_masks") if masks is not None else None
-        p_bits = self._check(bitmaps, (B, md, c.proto_h, c.proto_w), "detection_bitmaps", torch.uint8) if bitmaps is not None else None
+        # An output set of ours that has been checked before, with the same tensors in it, is not checked again: at
+        # batch 1 the seven checks cost more host time than the kernels take on the GPU.
+        cache = getattr(out, "_checked", None)
+        if cache is not None and cache[0] == B and all(out.get(k) is t for k, t in zip(_OUT_KEYS, cache[1])):
+            p_boxes, p_clsout, p_scores, p_num, p_aidx, p_masks, p_bits = cache[2]
+        else:
+            bitmaps = out.get("detection_bitmaps")
+            p_boxes = self._check(out["detection_boxes"], (B, md, 4), "detection_boxes")
+            p_clsout = self._check(out["detection_classes"], (B, md), "detection_classes")
+            p_scores = self._check(out["detection_scores"], (B, md), "detection_scores")
+            p_num = self._check(out["num_detections"], (B,), "num_detections", torch.int32)
+            aidx = out.get("detection_anchor_indices")
+            p_aidx = self._check(aidx, (B, md), "detection_anchor_indices", torch.int32) if aidx is not None else None
+            p_masks = self._check(masks, (B, md, c.proto_h, c.proto_w), "detection_masks") if masks is not None else None
+            p_bits = self._check(bitmaps, (B, md, c.proto_h, c.proto_w), "detection_bitmaps", torch.uint8) if bitmaps is not None else None
+            if not fresh and isinstance(out, OutputSet):
+                out._checked = (B, tuple(out.get(k) for k in _OUT_KEYS), (p_boxes, p_clsout, p_scores, p_num, p_aidx, p_masks, p_bits))
         stream = torch.cuda.current_stream(self.device).cuda_stream
         if isinstance(out, KeptOutputs):
             _lib.check(self._L.yp_run_kept(self._h, out._k, B, p_off, p_cls, p_coef, p_pri, p_proto, p_boxes, p_clsout,
@@ -172,7 +181,16 @@ class PostProcessor:
         return int(self._L.yp_scratch_bytes(self._h))
 
 
-class KeptOutputs(dict):
+_OUT_KEYS = ("detection_boxes", "detection_classes", "detection_scores", "num_detections", "detection_anchor_indices",
+             "detection_masks", "detection_bitmaps")
+
+
+class OutputSet(dict):
+    """The output tensors of PostProcessor.alloc_outputs: a dict that remembers having been checked (run())."""
+    _checked = None
+
+
+class KeptOutputs(OutputSet):
     """The output tensors of PostProcessor.alloc_kept together with the library's record of their masks' contents."""
     _L = None
     _k = None
@@ -198,6 +216,8 @@ class KeptOutputs(dict):
 
 def _as_device_tensor(x, device):
     if isinstance(x, torch.Tensor):
+        if x.dtype is torch.float32 and x.device == device:      # (the usual case: no dispatcher round trip)
+            return x if x.is_contiguous() else x.contiguous()
         t = x
     else:
         t = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32))
