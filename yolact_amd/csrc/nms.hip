@@ -470,7 +470,9 @@ __device__ __forceinline__ int select_topk_sorted(const Src& src, int n, int wan
 //        -1 (workgroup-uniform) if the bins do not isolate <= YP_SORT_MAX keys around the k-th (a score plateau):
 //        nothing has been selected and the caller takes the general path.
 // All threads must call it; k >= 1 and at most the number of valid keys.
-// (Tried in the per-class kernel as well - the cut of a group's pool to its best max_dets and the image's final
+// (In the per-class kernel - the cut of a group's pool to its best max_dets and the image's final selection, both
+//  of which hold their keys in registers - only the instantiation launched WITHOUT fill workgroups uses it.  Measured
+//  in the other one: the cut of a group's pool to its best max_dets and the image's final
 //  selection, both of which hold their keys in registers: 30.0 -> 28.4 us for the chain on tracked output sets (no
 //  fill beside it), nothing measurable under the fill, and +2-4 us at config 4, whose pools are a thousand EQUAL
 //  scores just below 1.0 ordered by anchor alone - every key in one bin, a thousand LDS atomics on one address - and
@@ -941,6 +943,7 @@ __device__ __forceinline__ void store_wt(float4* p, const float4 v) {
   store_wt(q + 1, ((u64)__builtin_bit_cast(uint32_t, v.w) << 32) | __builtin_bit_cast(uint32_t, v.z));
 }
 
+#define YP_POOL_CROWDED 0x40000000   // flag in a group's pool_count: the pool was cut from a crowd
 struct GroupShared {
   // One 24 KiB region with several lives.
   //   thread-per-candidate path:  bk (keys bucketed by class, while they are ranked), then box (per class the
@@ -1062,11 +1065,11 @@ __device__ __forceinline__ void group_nms_slow(const NmsArgs& p, int b, int g, i
     }
     base = kept;
   }
-  if (t == 0) store_wt(&p.pool_count[(size_t)b * p.ngroups + g], base);
+  if (t == 0) store_wt(&p.pool_count[(size_t)b * p.ngroups + g], base | YP_POOL_CROWDED);   // (an oversized group: see group_nms_body)
 }
 
 // Workgroup (g, b): the classes c of image b with (c-1) % ngroups == g (detection.py:217-239).
-template <int THREADS>
+template <int THREADS, bool ALONE>
 __device__ __forceinline__ void group_nms_body(const NmsArgs& p, int b, int g, GroupShared& gs) {
   constexpr int KPT = YP_GROUP_KPT;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -1252,29 +1255,57 @@ __device__ __forceinline__ void group_nms_body(const NmsArgs& p, int b, int g, G
   }
   __syncthreads();
   int np = gs.npool;
+  // A pool cut from a crowd (config 4: a thousand survivors, most of their scores EQUAL floats just below 1.0 and
+  // ordered by anchor alone) cannot be cut by score bins - every key lands in one bin, a thousand LDS atomics on one
+  // address: such a group goes straight to the general selection and tells the image's selection so with its count.
+  const int crowded = ALONE && np > 2 * YP_SORT_MAX ? YP_POOL_CROWDED : 0;
   const int want = min(p.max_dets, YP_SORT_MAX);
   if (np > want) {                                                // (workgroup-uniform)
+    int m = -1;
+    if (ALONE && !crowded) {
+      // (box[] has been swept: hist[] - which shares its memory - and the selection's scratch are free)
 #pragma unroll
-    for (int u = 0; u < KPT; ++u)
-      if (pslot[u] >= 0) gs.stage[pslot[u]] = key[u];             // (box[] has been swept: the stage takes its place)
-    __syncthreads();
-    const ListSrc ls{gs.stage, np};
-    np = select_topk_sorted<THREADS>(ls, np, want, gs.sh, nullptr, 0);
-    const u64 kth = gs.sh.key[np - 1];
+      for (int i = 0; i < YP_RADIX_BINS / THREADS; ++i) gs.hist[t * (YP_RADIX_BINS / THREADS) + i] = 0;
+      if (t < YP_SORT_MAX) gs.sh.rank[t] = 0;
+      if (t == 0) gs.sh.fill = 0;
+      __syncthreads();
+      bool valid[KPT];
+      int rk[KPT];
 #pragma unroll
-    for (int u = 0; u < KPT; ++u)
-      if (pslot[u] >= 0) pslot[u] = key[u] >= kth ? rank_desc(gs.sh.key, np, key[u]) : -1;
+      for (int u = 0; u < KPT; ++u) valid[u] = pslot[u] >= 0;
+      m = select_from_registers<THREADS, KPT>(key, valid, want, p.sel_base, p.sel_shift, gs.sh, rk);
+      if (m >= 0) {
+#pragma unroll
+        for (int u = 0; u < KPT; ++u)
+          if (pslot[u] >= 0) pslot[u] = rk[u] >= 0 && rk[u] < want ? rk[u] : -1;
+        np = want;
+      } else {
+        __syncthreads();
+      }
+    }
+    if (m < 0) {
+#pragma unroll
+      for (int u = 0; u < KPT; ++u)
+        if (pslot[u] >= 0) gs.stage[pslot[u]] = key[u];           // (box[] has been swept: the stage takes its place)
+      __syncthreads();
+      const ListSrc ls{gs.stage, np};
+      np = select_topk_sorted<THREADS>(ls, np, want, gs.sh, nullptr, 0);
+      const u64 kth = gs.sh.key[np - 1];
+#pragma unroll
+      for (int u = 0; u < KPT; ++u)
+        if (pslot[u] >= 0) pslot[u] = key[u] >= kth ? rank_desc(gs.sh.key, np, key[u]) : -1;
+    }
   }
 #pragma unroll
   for (int u = 0; u < KPT; ++u)
     if (pslot[u] >= 0) { store_wt(&pool[pslot[u]], key[u]); store_wt(&pbox[pslot[u]], box[u]); }
-  if (t == 0) store_wt(&p.pool_count[(size_t)b * p.ngroups + g], np);
+  if (t == 0) store_wt(&p.pool_count[(size_t)b * p.ngroups + g], np | crowded);
   STAMP(6);
 }
 
 // Per-class mode: cross-class top max_dets over the pooled survivors (detection.py:242-248), run by
 // the workgroup of the image's class group that finished last.
-template <int THREADS>
+template <int THREADS, bool ALONE>
 __device__ __forceinline__ void final_select_body(const NmsArgs& p, int b, GroupShared& gs) {
   SelectShared& sh = gs.sh;
   int* const start = gs.start;
@@ -1305,6 +1336,16 @@ __device__ __forceinline__ void final_select_body(const NmsArgs& p, int b, Group
   if (t < p.ngroups) cnt = p.pool_count[(size_t)b * p.ngroups + t];
   int part = 0;
   for (int i = t; i < p.parts; i += THREADS) part += p.seg_surv[(size_t)b * p.parts + i];
+  bool any_crowded = true;
+  if (ALONE) {
+    // (while the loads are under way) what the selection from registers expects to be zero
+    if (t == 0) { sh.hist = gs.hist; sh.fill = 0; }
+#pragma unroll
+    for (int i = 0; i < YP_RADIX_BINS / THREADS; ++i) gs.hist[t * (YP_RADIX_BINS / THREADS) + i] = 0;
+    if (t < YP_SORT_MAX) sh.rank[t] = 0;
+    any_crowded = __syncthreads_or((cnt & YP_POOL_CROWDED) != 0) != 0;
+  }
+  cnt &= ~YP_POOL_CROWDED;
 #ifdef YP_STAMPS
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   STAMP(13);
@@ -1318,7 +1359,36 @@ __device__ __forceinline__ void final_select_body(const NmsArgs& p, int b, Group
   const int n = start[p.ngroups];
   STAMP(1);
   int k = 0;
-  if (n > 0) {
+  bool done = false;
+  if (ALONE && n > 0 && !any_crowded) {
+    // every pooled key is in a register if no list is longer than the first batch (16 groups: always)
+    bool in_regs = true;
+    for (int g = 0; g < p.ngroups; ++g) in_regs = in_regs && (start[g + 1] - start[g]) <= lpp * YP_POOL_PRE;
+    if (in_regs) {                                 // (workgroup-uniform)
+      k = min(min(p.max_dets, YP_SORT_MAX), n);
+      const int ng = start[pg + 1] - start[pg];
+      bool valid[YP_POOL_PRE];
+      int rk[YP_POOL_PRE];
+#pragma unroll
+      for (int u = 0; u < YP_POOL_PRE; ++u) valid[u] = t < (p.ngroups << sft) && pq + u * lpp < ng;
+      const int m = select_from_registers<THREADS, YP_POOL_PRE>(src.pre, valid, k, p.sel_base, p.sel_shift, sh, rk);
+      if (m >= 0) {
+        STAMP(2);
+        // every thread that holds one of the selected keys writes that detection's row, at the rank it was told
+#pragma unroll
+        for (int u = 0; u < YP_POOL_PRE; ++u)
+          if (rk[u] >= 0 && rk[u] < k) {
+            const u64 key = src.pre[u];
+            const float4 bx = u < YP_POOL_PRE_BOX ? preb[u < YP_POOL_PRE_BOX ? u : 0] : plb[pq + u * lpp];
+            emit_row(p, b, rk[u], yp_key_score(key), yp_fin_key_class(key), min(yp_fin_key_anchor(key), p.A - 1), bx);
+          }
+        done = true;
+      } else {
+        __syncthreads();
+      }
+    }
+  }
+  if (n > 0 && !done) {
 #ifdef YP_STAMPS
     k = select_topk_sorted<THREADS>(src, n, min(p.max_dets, YP_SORT_MAX), sh, gs.stage, YP_GSTAGE_CAP, dbg_);
 #else
@@ -1379,7 +1449,11 @@ __global__ __launch_bounds__(THREADS, MIN_WAVES) void group_nms_kernel(const Nms
   return;
 #endif
   const int b = (int)blockIdx.x / p.ngroups, g = (int)blockIdx.x - b * p.ngroups;
-  group_nms_body<THREADS>(p, b, g, gs);
+  // ALONE: the instantiation launched without fill workgroups (tracked output sets).  Its time is the latency chain
+  // itself, and it has registers to spare: it takes the selections from registers (select_from_registers) that cost
+  // the other instantiation - spilling at its 80-register bound, and hidden under the fill anyway - more than they save.
+  constexpr bool ALONE = MIN_WAVES == YP_GROUP_MIN_WAVES_ALONE && YP_GROUP_MIN_WAVES_ALONE != YP_GROUP_MIN_WAVES;
+  group_nms_body<THREADS, ALONE>(p, b, g, gs);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pool stores have completed
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -1395,7 +1469,7 @@ __global__ __launch_bounds__(THREADS, MIN_WAVES) void group_nms_kernel(const Nms
   }
   __syncthreads();
   if (!gs.last) return;
-  final_select_body<THREADS>(p, b, gs);
+  final_select_body<THREADS, ALONE>(p, b, gs);
 }
 
 // The zero-fill alone (callers with no NMS launch to carry it: yp_assemble_masks; YP_TUNE_PREFILL=0).
